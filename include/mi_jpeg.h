@@ -1,0 +1,148 @@
+/*
+ * mi_jpeg.h -- C ABI of the MI355X-native JPEG path (libmijpeg.so).
+ *
+ * This is the drop-in boundary for the one hot path of OroChippw/Nvjpeg-ImageCompressor: everything the reference
+ * does through NVIDIA nvJPEG between `NvjpegCompressRunnerImpl::initCompressEnv` and
+ * `nvjpegEncodeRetrieveBitstream`. Each entry point names the reference interface it replaces
+ * (paths relative to the reference root, src/ImageCompressorDll/).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative MIJ_ERR_* code and
+ * NEVER calls exit() (the reference's CHECK_CUDA / CHECK_NVJPEG do, ImageCompressorImpl.cuh:16-34);
+ * `mij_last_error` returns a human-readable message for the last failure on that handle.
+ * One handle per thread; a handle is not re-entrant (same contract as the reference: one encoder state and one set
+ * of device planes per instance, ImageCompressorImpl.cuh:58-63).
+ * "device pointer" = HIP device memory on the handle's device; `stream` = a hipStream_t passed as void* (NULL = the
+ * null stream, which is what the reference encodes on, ImageCompressorImpl.cu:280).
+ */
+#ifndef MI_JPEG_H_
+#define MI_JPEG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIJ_API __attribute__((visibility("default")))
+
+/* Error codes */
+enum {
+  MIJ_OK = 0,
+  MIJ_ERR_INVALID_ARG = -1,
+  MIJ_ERR_HIP = -2,          /* a HIP runtime call failed (replaces CHECK_CUDA's exit(1)) */
+  MIJ_ERR_NO_DEVICE = -3,    /* no usable gfx950 device: the library has NO CPU fallback */
+  MIJ_ERR_NOT_READY = -4,    /* result requested before an encode was issued */
+  MIJ_ERR_OVERFLOW = -5,     /* output exceeded the capacity that could be allocated */
+  MIJ_ERR_BAD_STREAM = -6,   /* decoder: not a JPEG this decoder handles */
+  MIJ_ERR_ALLOC = -7
+};
+
+/* Chroma subsampling: same integer values as nvjpegChromaSubsampling_t, so code that passes
+ * NVJPEG_CSS_* ints keeps working (reference hard-codes NVJPEG_CSS_444, ImageCompressorImpl.cu:31). */
+enum { MIJ_CSS_444 = 0, MIJ_CSS_422 = 1, MIJ_CSS_420 = 2, MIJ_CSS_440 = 3, MIJ_CSS_411 = 4, MIJ_CSS_410 = 5 };
+
+/* Input layouts: same integer values as nvjpegInputFormat_t. Planar = three planes of `pitch` x height bytes,
+ * plane p at src + p * plane_stride (the reference's nvjpegImage_t with pitch = width and NVJPEG_INPUT_BGR,
+ * ImageCompressorImpl.cuh:61-62, .cu:33-37). Interleaved = cv::Mat CV_8UC3 rows (main.cpp:37). */
+enum { MIJ_INPUT_RGB = 3, MIJ_INPUT_BGR = 4, MIJ_INPUT_RGBI = 5, MIJ_INPUT_BGRI = 6 };
+
+#define MIJ_RESTART_AUTO (-1)
+
+typedef struct mij_encoder mij_encoder;
+
+typedef struct mij_encoder_params {
+  int width, height;       /* full image size; reference ctor args (ImageCompressor.h:27), default 8320 x 40000 */
+  int quality;             /* 1..100, IJG scaling; nvjpegEncoderParamsSetQuality (ImageCompressorImpl.cu:30) */
+  int optimized_huffman;   /* nvjpegEncoderParamsSetOptimizedHuffman (ImageCompressorImpl.cu:29) */
+  int css;                 /* MIJ_CSS_*; nvjpegEncoderParamsSetSamplingFactors (ImageCompressorImpl.cu:31) */
+  int restart_interval;    /* MCUs per restart interval (DRI); MIJ_RESTART_AUTO lets the library choose. The unit of
+                              GPU parallelism is one restart interval, so 0 (= no restart markers) is rejected. */
+  int device;              /* HIP device ordinal */
+  /* Strip sharding (multi-GPU). This encoder handles MCU rows [strip_mcu_row0, +strip_mcu_rows) of the
+   * full image; strip_mcu_rows == 0 means the whole image. The strip's first MCU must fall on a restart-interval
+   * boundary (guaranteed when restart_interval divides the MCUs per row, which AUTO always picks). */
+  int strip_mcu_row0, strip_mcu_rows;
+} mij_encoder_params;
+
+/* Geometry derived from the parameters (useful to callers that shard). */
+typedef struct mij_geometry {
+  int hs, vs;                  /* luma sampling factors */
+  int mcu_w, mcu_h;            /* MCU size in pixels */
+  int mcus_per_row, mcu_rows;  /* whole image */
+  int blocks_per_mcu;
+  int restart_interval;        /* resolved value */
+  int64_t strip_first_mcu, strip_mcus;
+  int strip_y0, strip_rows;    /* pixel rows of the full image this strip reads */
+} mij_geometry;
+
+/* Result of one encode on a strip (device resident; valid until the next encode on the handle). */
+typedef struct mij_result {
+  const uint8_t *d_buffer;   /* device buffer holding [header][entropy-coded data][EOI] */
+  size_t header_offset;      /* where SOI sits inside d_buffer */
+  size_t header_bytes;       /* SOI .. SOS header (same on every strip) */
+  size_t scan_offset;        /* = header_offset + header_bytes */
+  size_t scan_bytes;         /* entropy-coded bytes of this strip incl. RSTn markers between and after its intervals;
+                                the last strip of the image ends with EOI instead of a trailing RSTn */
+  size_t file_bytes;         /* header_bytes + scan_bytes: a complete JFIF file when the strip is the whole image */
+} mij_result;
+
+MIJ_API const char *mij_version(void);
+MIJ_API int mij_device_count(void);
+
+/* initCompressEnv (ImageCompressorImpl.cu:19-45): create handles, push parameters, allocate device workspace. */
+MIJ_API int mij_encoder_create(const mij_encoder_params *params, mij_encoder **out);
+/* destoryCompressEnv (ImageCompressorImpl.cu:47-65). NULL is a no-op. */
+MIJ_API void mij_encoder_destroy(mij_encoder *enc);
+MIJ_API int mij_encoder_geometry(const mij_encoder *enc, mij_geometry *out);
+MIJ_API const char *mij_last_error(const mij_encoder *enc);
+
+/* nvjpegEncodeImage (ImageCompressorImpl.cu:280): device-resident pixels -> device-resident bitstream, asynchronous
+ * on `stream`. d_src points at the first pixel row of THIS strip (row strip_y0 of the image). */
+MIJ_API int mij_encode_device(mij_encoder *enc, const void *d_src, size_t pitch, size_t plane_stride, int input_format,
+                              void *stream);
+
+/* The same work split at its only cross-GPU exchange point (optimised Huffman statistics):
+ *   mij_encode_transform : colour convert + downsample + FDCT + quantise (+ symbol statistics when optimised)
+ *   [caller all-reduces the statistics returned by mij_histogram_device across ranks, in place]
+ *   mij_encode_entropy   : Huffman table build + entropy coding + restart markers + headers */
+MIJ_API int mij_encode_transform(mij_encoder *enc, const void *d_src, size_t pitch, size_t plane_stride,
+                                 int input_format, void *stream);
+MIJ_API int mij_encode_entropy(mij_encoder *enc, void *stream);
+/* Device pointer to the 4 x 257 uint32 symbol statistics (DC luma, AC luma, DC chroma, AC chroma). */
+MIJ_API int mij_histogram_device(mij_encoder *enc, uint32_t **d_hist, size_t *count);
+/* Use caller-owned device memory (e.g. a framework tensor that a collective can reduce) for the statistics. */
+MIJ_API int mij_set_histogram_buffer(mij_encoder *enc, uint32_t *d_hist);
+
+/* Waits for `stream` work issued by the last encode and reports where the bitstream is. */
+MIJ_API int mij_encode_result(mij_encoder *enc, mij_result *out);
+
+/* nvjpegEncodeRetrieveBitstream (ImageCompressorImpl.cu:285-287), same two-call protocol: data == NULL -> *length
+ * receives the size; otherwise up to *length bytes are copied to host memory and *length is updated. */
+MIJ_API int mij_retrieve_bitstream(mij_encoder *enc, uint8_t *data, size_t *length);
+
+/* CompressWorker's marshalling (ImageCompressorImpl.cu:272-277) + encode + retrieve in one call, from host memory:
+ * uploads the interleaved / planar image once (no cv::split), encodes, returns a library-owned host buffer that stays
+ * valid until the next call on this handle. */
+MIJ_API int mij_encode_host(mij_encoder *enc, const uint8_t *src, size_t pitch, size_t plane_stride, int input_format,
+                            const uint8_t **jpeg, size_t *jpeg_bytes);
+
+/* Per-stage device times of the last encode in milliseconds (the reference prints one cudaEvent time,
+ * ImageCompressorImpl.cu:289-291): [0] transform [1] statistics [2] table build [3] entropy code [4] scan
+ * [5] stuff+compact [6] total. Requires mij_encoder_enable_timing(enc, 1) before the encode. */
+#define MIJ_NUM_STAGE_TIMES 7
+MIJ_API int mij_encoder_enable_timing(mij_encoder *enc, int on);
+MIJ_API int mij_stage_times(mij_encoder *enc, float ms[MIJ_NUM_STAGE_TIMES]);
+
+/* Debug / parity taps (device -> host copies of intermediate buffers; used by the parity tests). */
+MIJ_API int mij_debug_coefficients(mij_encoder *enc, int16_t *host_dst, size_t count);
+MIJ_API int mij_debug_tables(mij_encoder *enc, uint8_t *host_dst_4x273);
+
+/* Bench utility: fill device memory with rows [y0, y0+rows) of the SURVEY.md 8(d) synthetic image
+ * (RGB or BGR interleaved). */
+MIJ_API int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_JPEG_H_ */

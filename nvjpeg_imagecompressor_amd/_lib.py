@@ -1,0 +1,92 @@
+"""ctypes binding of libmijpeg.so (the C ABI in include/mi_jpeg.h).
+
+The product path. There is no CPU fallback here and nothing in this package imports oracle/: if the HIP library is
+missing or no MI355X is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmijpeg.so")
+
+MIJ_OK = 0
+MIJ_RESTART_AUTO = -1
+CSS = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5}
+INPUT_RGB, INPUT_BGR, INPUT_RGBI, INPUT_BGRI = 3, 4, 5, 6
+NUM_STAGE_TIMES = 7
+STAGE_NAMES = ("transform", "statistics", "tables", "entropy", "scan", "compact", "total")
+
+# every symbol include/mi_jpeg.h declares (tests/test_abi.py checks the library exports all of them)
+EXPORTS = (
+    "mij_version", "mij_device_count", "mij_encoder_create", "mij_encoder_destroy", "mij_encoder_geometry",
+    "mij_last_error", "mij_encode_device", "mij_encode_transform", "mij_encode_entropy", "mij_histogram_device",
+    "mij_set_histogram_buffer", "mij_encode_result", "mij_retrieve_bitstream", "mij_encode_host",
+    "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
+    "mij_synth_image_device",
+)
+
+
+class EncoderParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("optimized_huffman", C.c_int),
+                ("css", C.c_int), ("restart_interval", C.c_int), ("device", C.c_int),
+                ("strip_mcu_row0", C.c_int), ("strip_mcu_rows", C.c_int)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("hs", C.c_int), ("vs", C.c_int), ("mcu_w", C.c_int), ("mcu_h", C.c_int),
+                ("mcus_per_row", C.c_int), ("mcu_rows", C.c_int), ("blocks_per_mcu", C.c_int),
+                ("restart_interval", C.c_int), ("strip_first_mcu", C.c_int64), ("strip_mcus", C.c_int64),
+                ("strip_y0", C.c_int), ("strip_rows", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("d_buffer", C.c_void_p), ("header_offset", C.c_size_t), ("header_bytes", C.c_size_t),
+                ("scan_offset", C.c_size_t), ("scan_bytes", C.c_size_t), ("file_bytes", C.c_size_t)]
+
+
+class MiJpegError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libmijpeg.so. Raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiJpegError("%s is missing: build it with `python -m nvjpeg_imagecompressor_amd.build` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.mij_version.restype = C.c_char_p
+    L.mij_device_count.restype = C.c_int
+    L.mij_last_error.restype = C.c_char_p
+    L.mij_last_error.argtypes = [vp]
+    L.mij_encoder_create.argtypes = [C.POINTER(EncoderParams), C.POINTER(vp)]
+    L.mij_encoder_destroy.argtypes = [vp]
+    L.mij_encoder_destroy.restype = None
+    L.mij_encoder_geometry.argtypes = [vp, C.POINTER(Geometry)]
+    L.mij_encode_device.argtypes = [vp, vp, sz, sz, C.c_int, vp]
+    L.mij_encode_transform.argtypes = [vp, vp, sz, sz, C.c_int, vp]
+    L.mij_encode_entropy.argtypes = [vp, vp]
+    L.mij_histogram_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.mij_set_histogram_buffer.argtypes = [vp, vp]
+    L.mij_encode_result.argtypes = [vp, C.POINTER(Result)]
+    L.mij_retrieve_bitstream.argtypes = [vp, vp, C.POINTER(sz)]
+    L.mij_encode_host.argtypes = [vp, vp, sz, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    L.mij_encoder_enable_timing.argtypes = [vp, C.c_int]
+    L.mij_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mij_debug_coefficients.argtypes = [vp, vp, sz]
+    L.mij_debug_tables.argtypes = [vp, vp]
+    L.mij_synth_image_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, sz, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def check(rc, handle=None, what="mi_jpeg call"):
+    if rc != MIJ_OK:
+        msg = load().mij_last_error(handle)
+        raise MiJpegError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

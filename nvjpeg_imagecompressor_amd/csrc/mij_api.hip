@@ -1,0 +1,414 @@
+// mij_api.hip -- host side of the C ABI declared in include/mi_jpeg.h.
+// Owns the device workspace (the reference's "env", ImageCompressorImpl.cu:19-65) and sequences the kernels of
+// mij_kernels.hip on the caller's stream. There is no CPU fallback: without a HIP device every entry point fails.
+#include "../../include/mi_jpeg.h"
+#include "mij_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace mij;
+
+struct mij_encoder {
+  mij_encoder_params p{};
+  Geom g{};
+  std::string err;
+  Quant hq{};
+  Quant *d_qt = nullptr;
+  DeviceTables *d_tab = nullptr;
+  uint32_t *d_hist_own = nullptr, *d_hist = nullptr;
+  int16_t *d_coef = nullptr;
+  size_t coef_count = 0;
+  uint8_t *d_scratch = nullptr;
+  size_t slot_bytes = 0;
+  long long nseg = 0;
+  uint32_t *d_seg_bytes = nullptr, *d_seg_ff = nullptr;
+  unsigned long long *d_seg_off = nullptr;
+  uint8_t *d_out = nullptr;
+  size_t capacity = 0;  // scan-data capacity (bytes after HDR_AREA)
+  DeviceResult *d_res = nullptr, *h_res = nullptr;
+  uint8_t *d_src = nullptr;
+  size_t d_src_bytes = 0;
+  uint8_t *h_out = nullptr;
+  size_t h_out_cap = 0;
+  hipEvent_t ev[8]{};
+  bool ev_ok = false, timing = false, timed_run = false;
+  float ms[MIJ_NUM_STAGE_TIMES]{};
+  bool transformed = false, issued = false, static_tables_ready = false;
+  hipStream_t last_stream = nullptr;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(mij_encoder *e, int code, const char *what, hipError_t he = hipSuccess) {
+  std::string m = what;
+  if (he != hipSuccess) { m += ": "; m += hipGetErrorString(he); }
+  if (e) e->err = m; else g_create_err = m;
+  fprintf(stderr, "[ERROR] mi_jpeg: %s\n", m.c_str());
+  return code;
+}
+#define HIPCHK(e, x)                                                        \
+  do {                                                                      \
+    hipError_t he_ = (x);                                                   \
+    if (he_ != hipSuccess) return fail((e), MIJ_ERR_HIP, #x, he_);          \
+  } while (0)
+
+static const uint8_t kStdLumQ[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57,
+                                     69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64,
+                                     81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+static const uint8_t kStdChrQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                     99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+// IJG quality scaling (nvjpegEncoderParamsSetQuality semantics, reference ImageCompressorImpl.cu:30).
+static void make_quant(int quality, Quant &q) {
+  quality = std::min(100, std::max(1, quality));
+  const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+  for (int t = 0; t < 2; t++)
+    for (int i = 0; i < 64; i++) {
+      long v = ((long)(t ? kStdChrQ[i] : kStdLumQ[i]) * scale + 50L) / 100L;
+      v = std::min(255L, std::max(1L, v));
+      q.q[t][i] = (uint16_t)v;
+      const float d = (float)(8 * v);
+      q.recip[t][i] = 1.0f / d;
+      q.bias[t][i] = ((float)(4 * v) + 0.5f) * q.recip[t][i];
+    }
+}
+
+static int css_factors(int css, int &hs, int &vs) {
+  switch (css) {
+    case MIJ_CSS_444: hs = 1; vs = 1; return 0;
+    case MIJ_CSS_422: hs = 2; vs = 1; return 0;
+    case MIJ_CSS_420: hs = 2; vs = 2; return 0;
+    case MIJ_CSS_440: hs = 1; vs = 2; return 0;
+    case MIJ_CSS_411: hs = 4; vs = 1; return 0;
+    case MIJ_CSS_410: hs = 4; vs = 2; return 0;
+    default: return -1;
+  }
+}
+
+// Restart interval = unit of GPU parallelism (one wavefront each) and of strip sharding. AUTO picks a divisor of the
+// MCUs-per-row (so every MCU row, hence every strip, starts on an interval boundary) whose block count fills whole
+// 64-block batches as well as possible.
+static int choose_restart_interval(int mcux, int bpm) {
+  int best = 0;
+  double best_eff = 0;
+  for (int d = 1; d <= mcux; d++) {
+    if (mcux % d) continue;
+    const int nb = d * bpm;
+    if (nb < 128 || nb > 1024) continue;
+    const double eff = (double)nb / (64.0 * ((nb + 63) / 64));
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = d; }
+  }
+  if (best) return best;
+  if ((long long)mcux * bpm > 1024) return std::min(mcux, 65535);
+  int rows = std::max(1, 256 / (mcux * bpm));
+  return std::min(mcux * rows, 65535);
+}
+
+extern "C" {
+
+const char *mij_version(void) { return "mi_jpeg 0.1 (gfx950)"; }
+
+int mij_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *mij_last_error(const mij_encoder *enc) { return enc ? enc->err.c_str() : g_create_err.c_str(); }
+
+void mij_encoder_destroy(mij_encoder *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->p.device);
+  if (e->last_stream || e->issued) (void)hipStreamSynchronize(e->last_stream);
+  (void)hipFree(e->d_qt); (void)hipFree(e->d_tab); (void)hipFree(e->d_hist_own); (void)hipFree(e->d_coef);
+  (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off);
+  (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src);
+  if (e->h_res) (void)hipHostFree(e->h_res);
+  if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->ev_ok) for (auto &v : e->ev) (void)hipEventDestroy(v);
+  delete e;
+}
+
+int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
+  if (!p || !out) return fail(nullptr, MIJ_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  int hs, vs;
+  if (p->width <= 0 || p->height <= 0 || p->width > 65535 || p->height > 65535)
+    return fail(nullptr, MIJ_ERR_INVALID_ARG, "width/height must be in 1..65535");
+  if (p->quality < 1 || p->quality > 100) return fail(nullptr, MIJ_ERR_INVALID_ARG, "quality must be in 1..100");
+  if (css_factors(p->css, hs, vs)) return fail(nullptr, MIJ_ERR_INVALID_ARG, "unsupported chroma subsampling");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MIJ_ERR_NO_DEVICE, "no HIP device: mi_jpeg has no CPU fallback");
+  if (p->device < 0 || p->device >= ndev) return fail(nullptr, MIJ_ERR_INVALID_ARG, "device ordinal out of range");
+  HIPCHK(nullptr, hipSetDevice(p->device));
+
+  mij_encoder *e = new (std::nothrow) mij_encoder();
+  if (!e) return fail(nullptr, MIJ_ERR_ALLOC, "out of host memory");
+  e->p = *p;
+  Geom &g = e->g;
+  g.W = p->width; g.H = p->height; g.hs = hs; g.vs = vs; g.nl = hs * vs; g.bpm = g.nl + 2;
+  g.mcux = (g.W + 8 * hs - 1) / (8 * hs);
+  g.mcuy = (g.H + 8 * vs - 1) / (8 * vs);
+  g.wib0 = (g.W + 7) / 8; g.hib0 = (g.H + 7) / 8;
+  g.crows = (g.H + vs - 1) / vs;
+  g.quality = p->quality;
+  int ri = p->restart_interval;
+  if (ri == MIJ_RESTART_AUTO) ri = choose_restart_interval(g.mcux, g.bpm);
+  if (ri < 1 || ri > 65535) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "restart_interval must be 1..65535 MCUs (or MIJ_RESTART_AUTO)"); }
+  g.ri = ri;
+  int row0 = p->strip_mcu_row0, rows = p->strip_mcu_rows;
+  if (rows == 0) { row0 = 0; rows = g.mcuy; }
+  if (row0 < 0 || rows < 0 || row0 + rows > g.mcuy) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip outside the image"); }
+  g.mcu_first = (long long)row0 * g.mcux;
+  g.mcu_count = (long long)rows * g.mcux;
+  if (g.mcu_first % ri) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not start on a restart-interval boundary"); }
+  g.last_strip = (row0 + rows == g.mcuy);
+  if (!g.last_strip && (g.mcu_count % ri)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not end on a restart-interval boundary"); }
+  g.y_origin = row0 * 8 * vs;
+  e->nseg = (g.mcu_count + ri - 1) / ri;
+  e->coef_count = (size_t)g.mcu_count * g.bpm * 64;
+  e->slot_bytes = (((size_t)ri * g.bpm * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
+  e->capacity = e->coef_count + 65536;
+  make_quant(p->quality, e->hq);
+
+#define CRCHK(x) do { hipError_t he_ = (x); if (he_ != hipSuccess) { int rc_ = fail(nullptr, MIJ_ERR_HIP, #x, he_); mij_encoder_destroy(e); return rc_; } } while (0)
+  CRCHK(hipMalloc(&e->d_qt, sizeof(Quant)));
+  CRCHK(hipMemcpy(e->d_qt, &e->hq, sizeof(Quant), hipMemcpyHostToDevice));
+  CRCHK(hipMalloc(&e->d_tab, sizeof(DeviceTables)));
+  CRCHK(hipMalloc(&e->d_hist_own, 4 * 257 * sizeof(uint32_t)));
+  CRCHK(hipMemset(e->d_hist_own, 0, 4 * 257 * sizeof(uint32_t)));
+  e->d_hist = e->d_hist_own;
+  CRCHK(hipMalloc(&e->d_coef, e->coef_count * sizeof(int16_t)));
+  CRCHK(hipMalloc(&e->d_scratch, e->slot_bytes * (size_t)e->nseg));
+  CRCHK(hipMalloc(&e->d_seg_bytes, (size_t)e->nseg * sizeof(uint32_t)));
+  CRCHK(hipMalloc(&e->d_seg_ff, (size_t)e->nseg * sizeof(uint32_t)));
+  CRCHK(hipMalloc(&e->d_seg_off, (size_t)e->nseg * sizeof(unsigned long long)));
+  CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity));
+  CRCHK(hipMalloc(&e->d_res, sizeof(DeviceResult)));
+  CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
+  for (auto &v : e->ev) CRCHK(hipEventCreate(&v));
+  e->ev_ok = true;
+#undef CRCHK
+  *out = e;
+  return MIJ_OK;
+}
+
+int mij_encoder_geometry(const mij_encoder *e, mij_geometry *o) {
+  if (!e || !o) return MIJ_ERR_INVALID_ARG;
+  const Geom &g = e->g;
+  o->hs = g.hs; o->vs = g.vs; o->mcu_w = 8 * g.hs; o->mcu_h = 8 * g.vs;
+  o->mcus_per_row = g.mcux; o->mcu_rows = g.mcuy; o->blocks_per_mcu = g.bpm; o->restart_interval = g.ri;
+  o->strip_first_mcu = g.mcu_first; o->strip_mcus = g.mcu_count;
+  o->strip_y0 = g.y_origin;
+  const int y1 = std::min(g.H, (int)((g.mcu_first + g.mcu_count) / g.mcux) * 8 * g.vs);
+  o->strip_rows = y1 - g.y_origin;
+  return MIJ_OK;
+}
+
+int mij_encoder_enable_timing(mij_encoder *e, int on) {
+  if (!e) return MIJ_ERR_INVALID_ARG;
+  e->timing = on != 0;
+  return MIJ_OK;
+}
+
+int mij_set_histogram_buffer(mij_encoder *e, uint32_t *d_hist) {
+  if (!e) return MIJ_ERR_INVALID_ARG;
+  e->d_hist = d_hist ? d_hist : e->d_hist_own;
+  return MIJ_OK;
+}
+
+int mij_histogram_device(mij_encoder *e, uint32_t **d_hist, size_t *count) {
+  if (!e || !d_hist) return MIJ_ERR_INVALID_ARG;
+  *d_hist = e->d_hist;
+  if (count) *count = 4 * 257;
+  return MIJ_OK;
+}
+
+int mij_encode_transform(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *stream) {
+  if (!e || !d_src) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
+  if (!interleaved && fmt != MIJ_INPUT_RGB && fmt != MIJ_INPUT_BGR) return fail(e, MIJ_ERR_INVALID_ARG, "unknown input format");
+  const Geom &g = e->g;
+  if (pitch < (size_t)g.W * (interleaved ? 3 : 1)) return fail(e, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  e->last_stream = s;
+  e->timed_run = e->timing;
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[0], s));
+  TransformArgs a{};
+  a.src = (const uint8_t *)d_src; a.pitch = pitch; a.plane_stride = plane_stride;
+  const bool rgb_order = fmt == MIJ_INPUT_RGB || fmt == MIJ_INPUT_RGBI;
+  const int kR[3] = {19595, -11059, 32768}, kB[3] = {7471, 32768, -5329};
+  for (int i = 0; i < 3; i++) { a.kA[i] = rgb_order ? kR[i] : kB[i]; a.kC[i] = rgb_order ? kB[i] : kR[i]; }
+  a.coef = e->d_coef; a.qt = e->d_qt; a.hist = e->d_hist;
+  HIPCHK(e, launch_transform(g, a, interleaved ? 1 : 0, s));
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
+  if (e->p.optimized_huffman) {
+    HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
+    HIPCHK(e, launch_histogram(g, e->d_coef, e->d_hist, s));
+  }
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
+  e->transformed = true;
+  return MIJ_OK;
+}
+
+static int run_tail(mij_encoder *e, hipStream_t s, bool tables) {
+  const Geom &g = e->g;
+  if (tables) HIPCHK(e, launch_build_tables(g, e->d_hist, e->p.optimized_huffman ? 1 : 0, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
+  return MIJ_OK;
+}
+
+int mij_encode_entropy(mij_encoder *e, void *stream) {
+  if (!e) return MIJ_ERR_INVALID_ARG;
+  if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_entropy called before mij_encode_transform");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  e->last_stream = s;
+  const Geom &g = e->g;
+  // Fixed (Annex K) tables and the header do not depend on the image: built once per handle.
+  if (e->p.optimized_huffman || !e->static_tables_ready) {
+    int rc = run_tail(e, s, true);
+    if (rc) return rc;
+    e->static_tables_ready = true;
+  }
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
+  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, s));
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
+  HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_res, s));
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
+  HIPCHK(e, launch_compact(g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->nseg, e->d_out + HDR_AREA,
+                           e->capacity, e->d_res, s));
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[6], s));
+  HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
+  e->issued = true;
+  return MIJ_OK;
+}
+
+int mij_encode_device(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *stream) {
+  int rc = mij_encode_transform(e, d_src, pitch, plane_stride, fmt, stream);
+  if (rc) return rc;
+  return mij_encode_entropy(e, stream);
+}
+
+int mij_encode_result(mij_encoder *e, mij_result *o) {
+  if (!e || !o) return MIJ_ERR_INVALID_ARG;
+  if (!e->issued) return fail(e, MIJ_ERR_NOT_READY, "no encode has been issued on this handle");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  if (e->h_res->scan_bytes > e->capacity) {
+    // Output larger than the preallocated buffer (very high quality on noise): grow it and redo header + compaction.
+    const size_t need = (size_t)e->h_res->scan_bytes + 65536;
+    uint8_t *nb = nullptr;
+    if (hipMalloc(&nb, HDR_AREA + need) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
+    (void)hipFree(e->d_out);
+    e->d_out = nb; e->capacity = need;
+    hipStream_t s = e->last_stream;
+    HIPCHK(e, launch_build_tables(e->g, e->d_hist, e->p.optimized_huffman ? 1 : 0, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
+    HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->nseg, e->d_out + HDR_AREA,
+                             e->capacity, e->d_res, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+  }
+  if (e->timed_run) {
+    // ev: 0 start, 1 after transform, 2 after statistics, 3 after tables, 4 after encode, 5 after scan, 6 after compact
+    for (int i = 0; i < 6; i++) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]) != hipSuccess) t = -1.f;
+      e->ms[i] = t;
+    }
+    float t = 0;
+    if (hipEventElapsedTime(&t, e->ev[0], e->ev[6]) != hipSuccess) t = -1.f;
+    e->ms[6] = t;
+  }
+  const size_t hb = e->h_res->header_bytes;
+  o->d_buffer = e->d_out;
+  o->header_offset = HDR_AREA - hb;
+  o->header_bytes = hb;
+  o->scan_offset = HDR_AREA;
+  o->scan_bytes = (size_t)e->h_res->scan_bytes;
+  o->file_bytes = hb + o->scan_bytes;
+  return MIJ_OK;
+}
+
+int mij_retrieve_bitstream(mij_encoder *e, uint8_t *data, size_t *length) {
+  if (!e || !length) return MIJ_ERR_INVALID_ARG;
+  mij_result r;
+  int rc = mij_encode_result(e, &r);
+  if (rc) return rc;
+  if (!data) { *length = r.file_bytes; return MIJ_OK; }
+  const size_t n = std::min(*length, r.file_bytes);
+  HIPCHK(e, hipMemcpy(data, r.d_buffer + r.header_offset, n, hipMemcpyDeviceToHost));
+  *length = n;
+  return MIJ_OK;
+}
+
+int mij_encode_host(mij_encoder *e, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt, const uint8_t **jpeg,
+                    size_t *jpeg_bytes) {
+  if (!e || !src || !jpeg || !jpeg_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  mij_geometry geo;
+  mij_encoder_geometry(e, &geo);
+  const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
+  const size_t bytes = interleaved ? pitch * (size_t)geo.strip_rows : plane_stride * 2 + pitch * (size_t)geo.strip_rows;
+  if (bytes > e->d_src_bytes) {
+    (void)hipFree(e->d_src);
+    e->d_src = nullptr; e->d_src_bytes = 0;
+    HIPCHK(e, hipMalloc(&e->d_src, bytes));
+    e->d_src_bytes = bytes;
+  }
+  HIPCHK(e, hipMemcpy(e->d_src, src, bytes, hipMemcpyHostToDevice));  // one upload; no cv::split (reference .cu:273-277)
+  int rc = mij_encode_device(e, e->d_src, pitch, plane_stride, fmt, nullptr);
+  if (rc) return rc;
+  mij_result r;
+  rc = mij_encode_result(e, &r);
+  if (rc) return rc;
+  if (r.file_bytes > e->h_out_cap) {
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    e->h_out = nullptr; e->h_out_cap = 0;
+    const size_t cap = r.file_bytes + r.file_bytes / 8 + 4096;
+    HIPCHK(e, hipHostMalloc(&e->h_out, cap, hipHostMallocDefault));
+    e->h_out_cap = cap;
+  }
+  HIPCHK(e, hipMemcpy(e->h_out, r.d_buffer + r.header_offset, r.file_bytes, hipMemcpyDeviceToHost));
+  *jpeg = e->h_out;
+  *jpeg_bytes = r.file_bytes;
+  return MIJ_OK;
+}
+
+int mij_stage_times(mij_encoder *e, float ms[MIJ_NUM_STAGE_TIMES]) {
+  if (!e || !ms) return MIJ_ERR_INVALID_ARG;
+  if (!e->timed_run) return fail(e, MIJ_ERR_NOT_READY, "timing was not enabled for the last encode");
+  memcpy(ms, e->ms, sizeof(e->ms));
+  return MIJ_OK;
+}
+
+int mij_debug_coefficients(mij_encoder *e, int16_t *dst, size_t count) {
+  if (!e || !dst) return MIJ_ERR_INVALID_ARG;
+  HIPCHK(e, hipSetDevice(e->p.device));
+  HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  HIPCHK(e, hipMemcpy(dst, e->d_coef, std::min(count, e->coef_count) * sizeof(int16_t), hipMemcpyDeviceToHost));
+  return MIJ_OK;
+}
+
+int mij_debug_tables(mij_encoder *e, uint8_t *dst) {
+  if (!e || !dst) return MIJ_ERR_INVALID_ARG;
+  HIPCHK(e, hipSetDevice(e->p.device));
+  HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  DeviceTables t;
+  HIPCHK(e, hipMemcpy(&t, e->d_tab, sizeof(t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; i++) { memcpy(dst + i * 273, t.bits[i], 17); memcpy(dst + i * 273 + 17, t.vals[i], 256); }
+  return MIJ_OK;
+}
+
+int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream) {
+  if (!d_dst || width <= 0 || rows <= 0 || pitch < (size_t)width * 3) return MIJ_ERR_INVALID_ARG;
+  hipError_t he = launch_synth((uint8_t *)d_dst, width, y0, rows, pitch, bgr, (hipStream_t)stream);
+  return he == hipSuccess ? MIJ_OK : MIJ_ERR_HIP;
+}
+
+}  // extern "C"

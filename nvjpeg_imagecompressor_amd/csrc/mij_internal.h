@@ -1,0 +1,76 @@
+// mij_internal.h -- shared declarations between the HIP kernels (mij_kernels.hip) and the C-ABI host code
+// (mij_api.hip). Not part of the public boundary (that is include/mi_jpeg.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace mij {
+
+// ---- data layout in HBM (DESIGN.md "Data layout") -------------------------------------------------------------
+// coefficients : int16 [strip_mcus][blocks_per_mcu][64], blocks in MCU (scan) order, coefficients in zig-zag order.
+//                One restart interval = `ri` consecutive MCUs = one contiguous range of this buffer.
+// statistics   : uint32 [4][257]  DC luma, AC luma, DC chroma, AC chroma (index 256 unused on device).
+// tables       : DeviceTables (below): bits/vals for the DHT segments + the encoder LUT.
+// scratch      : uint8 [nseg][slot_bytes]  un-stuffed entropy-coded bytes of each restart interval.
+// seg_bytes / seg_ff / seg_off : uint32/uint32/uint64 [nseg]
+// out          : uint8 [HDR_AREA + capacity]  header right-aligned in the first HDR_AREA bytes, then the scan data.
+
+constexpr int HDR_AREA = 2048;          // >= largest possible baseline header (SOI..SOS with four full DHTs = 1737 B)
+constexpr int LUT_DC_L = 0, LUT_AC_L = 16, LUT_DC_C = 272, LUT_AC_C = 288, LUT_SIZE = 544;
+constexpr int MAX_BLOCK_WORDS = 53;     // ceil((16+11 + 63*(16+10)) / 32) + 1 : worst-case bits of one block
+constexpr int MAX_BLOCK_BYTES = 212;
+
+struct Quant {            // natural (row-major) coefficient order; [0] luma [1] chroma
+  float recip[2][64];     // 1 / (8 q)
+  float bias[2][64];      // (4 q + 0.5) / (8 q)
+  uint16_t q[2][64];
+};
+
+struct DeviceTables {
+  uint8_t bits[4][17];    // [DC luma, AC luma, DC chroma, AC chroma]
+  uint8_t vals[4][256];
+  uint32_t nvals[4];
+  uint32_t lut[LUT_SIZE]; // (code << 5) | length, indexed LUT_xx + symbol
+};
+
+struct DeviceResult {     // written by the scan kernel, copied to pinned host memory
+  uint64_t scan_bytes;
+  uint32_t header_bytes;
+  uint32_t flags;
+};
+
+struct Geom {
+  int W, H;               // full image
+  int hs, vs, bpm, nl;    // luma sampling, blocks per MCU, luma blocks per MCU
+  int mcux, mcuy;         // whole image
+  int wib0, hib0;         // luma width / height in real blocks
+  int crows;              // chroma rows produced by real downsampling = ceil(H / vs)
+  int ri;                 // restart interval in MCUs
+  long long mcu_first, mcu_count;  // this strip
+  int y_origin;           // image row of the strip's first source row
+  int last_strip;
+  int quality;
+};
+
+struct TransformArgs {
+  const uint8_t *src; size_t pitch, plane_stride;
+  int kA[3], kC[3];       // colour matrix rows for the first / third stored channel (Y, Cb, Cr); G is fixed
+  int16_t *coef; const Quant *qt; uint32_t *hist;
+};
+
+// launchers (mij_kernels.hip)
+hipError_t launch_transform(const Geom &g, const TransformArgs &a, int interleaved, hipStream_t s);
+hipError_t launch_histogram(const Geom &g, const int16_t *coef, uint32_t *hist, hipStream_t s);
+hipError_t launch_build_tables(const Geom &g, const uint32_t *hist, int optimize, const Quant *qt, DeviceTables *tab,
+                               uint8_t *out, DeviceResult *res, hipStream_t s);
+hipError_t launch_encode(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
+                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, hipStream_t s);
+hipError_t launch_scan(const uint32_t *seg_bytes, const uint32_t *seg_ff, unsigned long long *seg_off, long long nseg,
+                       DeviceResult *res, hipStream_t s);
+hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_bytes, const uint32_t *seg_bytes,
+                          const unsigned long long *seg_off, long long nseg, uint8_t *out_scan, size_t capacity,
+                          const DeviceResult *res, hipStream_t s);
+hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
+
+}  // namespace mij

@@ -1,0 +1,190 @@
+"""Python host layer over the C ABI: an Encoder handle object plus a mirror of the reference's
+`NvjpegCompressRunner` class surface (reference src/ImageCompressorDll/ImageCompressor.h:22-42) for hosts that drive
+the path from Python. numpy arrays stand in for cv::Mat (H x W x 3 uint8, BGR, as cv::imread returns).
+
+Nothing here computes JPEG arithmetic: every call goes to libmijpeg.so (HIP). No CPU fallback.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import CSS, INPUT_BGR, INPUT_BGRI, INPUT_RGB, INPUT_RGBI, MIJ_RESTART_AUTO, MiJpegError
+
+_FMT = {"rgb": INPUT_RGBI, "bgr": INPUT_BGRI, "rgb_planar": INPUT_RGB, "bgr_planar": INPUT_BGR}
+
+
+def _css_value(css):
+    if isinstance(css, str):
+        return CSS[css.replace(":", "")]
+    return int(css)
+
+
+class Encoder:
+    """One encoder state + device workspace (initCompressEnv / destoryCompressEnv, reference ImageCompressorImpl.cu:19-65)."""
+
+    def __init__(self, width, height, quality=95, optimized_huffman=True, css=0, restart_interval=MIJ_RESTART_AUTO,
+                 device=0, strip_mcu_row0=0, strip_mcu_rows=0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        p = _lib.EncoderParams(width, height, quality, int(bool(optimized_huffman)), _css_value(css),
+                               restart_interval, device, strip_mcu_row0, strip_mcu_rows)
+        rc = self._L.mij_encoder_create(C.byref(p), C.byref(self._h))
+        if rc:
+            msg = self._L.mij_last_error(None)
+            self._h = C.c_void_p()
+            raise MiJpegError("mij_encoder_create failed (rc=%d): %s" % (rc, msg.decode() if msg else "?"))
+        g = _lib.Geometry()
+        _lib.check(self._L.mij_encoder_geometry(self._h, C.byref(g)), self._h)
+        self.geometry = {f[0]: getattr(g, f[0]) for f in g._fields_}
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.mij_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- device-resident path (the timed path) -------------------------------------------------------------------
+    def encode_device(self, d_ptr, pitch, fmt="bgr", plane_stride=0, stream=0):
+        _lib.check(self._L.mij_encode_device(self._h, C.c_void_p(d_ptr), pitch, plane_stride, _FMT[fmt],
+                                             C.c_void_p(stream)), self._h, "mij_encode_device")
+
+    def transform(self, d_ptr, pitch, fmt="bgr", plane_stride=0, stream=0):
+        _lib.check(self._L.mij_encode_transform(self._h, C.c_void_p(d_ptr), pitch, plane_stride, _FMT[fmt],
+                                                C.c_void_p(stream)), self._h, "mij_encode_transform")
+
+    def entropy(self, stream=0):
+        _lib.check(self._L.mij_encode_entropy(self._h, C.c_void_p(stream)), self._h, "mij_encode_entropy")
+
+    def set_histogram_buffer(self, d_ptr):
+        _lib.check(self._L.mij_set_histogram_buffer(self._h, C.c_void_p(d_ptr)), self._h)
+
+    def result(self):
+        r = _lib.Result()
+        _lib.check(self._L.mij_encode_result(self._h, C.byref(r)), self._h, "mij_encode_result")
+        return {f[0]: getattr(r, f[0]) for f in r._fields_}
+
+    def retrieve(self):
+        """nvjpegEncodeRetrieveBitstream protocol (reference .cu:285-287): size query, then copy."""
+        n = C.c_size_t(0)
+        _lib.check(self._L.mij_retrieve_bitstream(self._h, None, C.byref(n)), self._h, "mij_retrieve_bitstream")
+        buf = np.empty(n.value, np.uint8)
+        _lib.check(self._L.mij_retrieve_bitstream(self._h, buf.ctypes.data, C.byref(n)), self._h)
+        return buf[:n.value].tobytes()
+
+    # -- host path (CompressWorker, reference .cu:269-294) --------------------------------------------------------
+    def encode_host(self, img, fmt="bgr"):
+        img = np.ascontiguousarray(img, np.uint8)
+        if fmt in ("rgb", "bgr"):
+            pitch, plane = img.shape[1] * 3, 0
+        else:
+            pitch, plane = img.shape[2], img.shape[1] * img.shape[2]
+        out, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self._L.mij_encode_host(self._h, img.ctypes.data, pitch, plane, _FMT[fmt], C.byref(out), C.byref(n)),
+                   self._h, "mij_encode_host")
+        return C.string_at(out.value, n.value)
+
+    # -- instrumentation -------------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        _lib.check(self._L.mij_encoder_enable_timing(self._h, int(on)), self._h)
+
+    def stage_times(self):
+        ms = (C.c_float * _lib.NUM_STAGE_TIMES)()
+        _lib.check(self._L.mij_stage_times(self._h, ms), self._h)
+        return dict(zip(_lib.STAGE_NAMES, [float(v) for v in ms]))
+
+    def debug_coefficients(self):
+        g = self.geometry
+        out = np.empty((g["strip_mcus"], g["blocks_per_mcu"], 64), np.int16)
+        _lib.check(self._L.mij_debug_coefficients(self._h, out.ctypes.data, out.size), self._h)
+        return out
+
+    def debug_tables(self):
+        out = np.zeros((4, 273), np.uint8)
+        _lib.check(self._L.mij_debug_tables(self._h, out.ctypes.data), self._h)
+        return out
+
+
+def synth_image_device(d_ptr, width, y0, rows, pitch, bgr=False, stream=0):
+    L = _lib.load()
+    _lib.check(L.mij_synth_image_device(C.c_void_p(d_ptr), width, y0, rows, pitch, int(bgr), C.c_void_p(stream)),
+               None, "mij_synth_image_device")
+
+
+class NvjpegCompressRunner:
+    """Mirror of the reference facade (ImageCompressor.h:22-42, ImageCompressor.cpp:14-101): same method names,
+    argument meaning and failure convention (empty result + run_state 0; nothing ever exit()s).
+
+    Additive extensions: css / restart_interval constructor keywords, in-memory decode.
+    `run_state` is returned as the second element of a tuple because Python has no out-parameters.
+    """
+
+    def __init__(self, width=8320, height=40000, quality=95, optimize=True, css=0, restart_interval=MIJ_RESTART_AUTO,
+                 device=0, verbose=True):
+        self.width, self.height, self.quality, self.optimize = width, height, quality, optimize
+        self.css, self.restart_interval, self.device, self.verbose = css, restart_interval, device, verbose
+        self._enc = None
+
+    def buildCompressEnv(self):
+        if self._enc is None:  # a second build is a no-op (the reference leaks here)
+            self._enc = Encoder(self.width, self.height, self.quality, self.optimize, self.css, self.restart_interval,
+                                self.device)
+            self._enc.enable_timing(True)
+
+    def deleteCompressEnv(self):
+        if self._enc is not None:
+            self._enc.close()
+            self._enc = None
+
+    def buildDecodeEnv(self):
+        pass
+
+    def deleteDecodeEnv(self):
+        pass
+
+    def compress(self, image):
+        """image: H x W x 3 uint8 BGR (cv::Mat CV_8UC3). Returns (bytes, run_state)."""
+        t0 = time.perf_counter()
+        out = b""
+        try:
+            if self._enc is None:
+                raise MiJpegError("compress() before buildCompressEnv()")
+            image = np.asarray(image)
+            if image.dtype != np.uint8 or image.ndim != 3 or image.shape != (self.height, self.width, 3):
+                raise MiJpegError("image must be uint8 %dx%dx3, got %s %s" % (self.height, self.width, image.dtype,
+                                                                               image.shape))
+            out = self._enc.encode_host(image, "bgr")
+            if self.verbose:
+                print("=> Compress Cost time : %gms" % self._enc.stage_times()["total"])
+        except MiJpegError as e:
+            print("[ERROR] Exception caught: %s" % e)
+            out = b""
+        if self.verbose:
+            print("[INFO] NvjpegCompressRunner Compress Func Cost Time : %d ms" % int((time.perf_counter() - t0) * 1e3))
+        return out, (0 if not out else 1)
+
+    def save(self, save_path, obuffer):
+        try:
+            with open(save_path, "wb") as f:
+                f.write(obuffer)
+        except OSError as e:
+            print("Exception caught: %s" % e)
+
+    def __del__(self):
+        try:
+            self.deleteCompressEnv()
+        except Exception:
+            pass

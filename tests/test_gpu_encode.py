@@ -1,0 +1,119 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle (bit exact)."""
+import io
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CSS_ALL = [0, 1, 2, 3, 4, 5]
+
+
+def _img(oracle, W, H, kind, seed=0):
+    if kind == "synth":
+        return oracle.synth_rgb(W, H)
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    if kind == "flat":
+        return np.full((H, W, 3), 77, np.uint8)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("css", CSS_ALL)
+@pytest.mark.parametrize("size", [(512, 512), (64, 48), (8, 8), (1, 1), (17, 33), (100, 75), (129, 65), (250, 3), (1040, 136)])
+def test_coefficients_match_oracle(mij, oracle, css, size):
+    W, H = size
+    img = _img(oracle, W, H, "synth")
+    with mij.Encoder(W, H, 95, True, css) as enc:
+        enc.encode_host(img, "rgb")
+        got = enc.debug_coefficients()
+    want = oracle.coefficients(img, 95, css)
+    assert got.shape == want.shape
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, "first mismatches (mcu, blk, k): %s" % bad[:5].tolist()
+
+
+@pytest.mark.parametrize("css", CSS_ALL)
+@pytest.mark.parametrize("optimize", [False, True])
+@pytest.mark.parametrize("size,kind", [((512, 512), "synth"), ((100, 75), "noise"), ((17, 33), "synth"), ((64, 64), "flat"),
+                                       ((1040, 136), "noise")])
+def test_file_bytes_match_oracle(mij, oracle, css, optimize, size, kind):
+    W, H = size
+    img = _img(oracle, W, H, kind, seed=css)
+    for q in (95, 30, 100):
+        with mij.Encoder(W, H, q, optimize, css) as enc:
+            ri = enc.geometry["restart_interval"]
+            got = enc.encode_host(img, "rgb")
+        want = oracle.encode(img, q, css, optimize, ri)
+        assert len(got) == len(want), (q, len(got), len(want))
+        assert got == want, "q=%d first diff at %d" % (q, next(i for i in range(len(want)) if got[i] != want[i]))
+
+
+@pytest.mark.parametrize("fmt", ["rgb", "bgr", "rgb_planar", "bgr_planar"])
+def test_input_formats(mij, oracle, fmt):
+    W, H = 136, 72
+    rgb = _img(oracle, W, H, "synth")
+    if fmt == "rgb":
+        arr = rgb
+    elif fmt == "bgr":
+        arr = rgb[..., ::-1]
+    elif fmt == "rgb_planar":
+        arr = rgb.transpose(2, 0, 1)
+    else:
+        arr = rgb[..., ::-1].transpose(2, 0, 1)
+    with mij.Encoder(W, H, 95, True, 1) as enc:
+        ri = enc.geometry["restart_interval"]
+        got = enc.encode_host(np.ascontiguousarray(arr), fmt)
+    assert got == oracle.encode(rgb, 95, 1, True, ri)
+
+
+def test_explicit_restart_intervals(mij, oracle):
+    W, H = 256, 64
+    img = _img(oracle, W, H, "noise", 3)
+    for ri in (1, 3, 7, 16, 64, 1000):
+        with mij.Encoder(W, H, 90, True, 2, restart_interval=ri) as enc:
+            got = enc.encode_host(img, "rgb")
+        assert got == oracle.encode(img, 90, 2, True, ri), ri
+
+
+def test_stock_decoder_roundtrip_and_psnr(mij, oracle):
+    from PIL import Image
+    W, H = 512, 512
+    img = _img(oracle, W, H, "synth")
+    with mij.Encoder(W, H, 95, False, 0, restart_interval=64) as enc:
+        got = enc.encode_host(img, "rgb")
+    dec = np.asarray(Image.open(io.BytesIO(got)).convert("RGB"))
+    # config 1 of BASELINE.json: libjpeg-turbo gives 35.688 dB on this input; same coefficients => same PSNR
+    assert abs(oracle.psnr(img, dec) - 35.688) < 0.05
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", quality=95, subsampling=0, restart_marker_blocks=64)
+    assert got == b.getvalue()
+
+
+def test_repeat_encodes_are_identical_and_timed(mij, oracle):
+    W, H = 512, 256
+    img = _img(oracle, W, H, "synth")
+    with mij.Encoder(W, H, 95, True, 1) as enc:
+        enc.enable_timing(True)
+        a = enc.encode_host(img, "rgb")
+        b = enc.encode_host(img, "rgb")
+        t = enc.stage_times()
+    assert a == b
+    assert t["total"] > 0
+
+
+def test_reference_facade(mij, oracle, tmp_path, capsys):
+    W, H = 208, 120
+    bgr = _img(oracle, W, H, "synth")[..., ::-1]
+    r = mij.NvjpegCompressRunner(W, H, 95, True)
+    r.buildCompressEnv()
+    out, state = r.compress(np.ascontiguousarray(bgr))
+    assert state == 1 and out[:2] == b"\xff\xd8" and out[-2:] == b"\xff\xd9"
+    bad, state = r.compress(np.zeros((H + 1, W, 3), np.uint8))  # wrong size: reference overruns, we refuse
+    assert state == 0 and bad == b""
+    r.save(str(tmp_path / "o.jpg"), out)
+    assert (tmp_path / "o.jpg").read_bytes() == out
+    r.deleteCompressEnv()
+    assert "Compress Cost time" in capsys.readouterr().out

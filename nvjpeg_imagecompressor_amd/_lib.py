@@ -49,6 +49,33 @@ class MiJpegError(RuntimeError):
 
 
 _lib = None
+HIP_RUNTIME = None  # path of the HIP runtime libmijpeg.so was bound to
+
+
+def _bind_hip_runtime():
+    """libmijpeg.so carries no DT_NEEDED for libamdhip64 (build.py): make exactly ONE HIP runtime global before it
+    loads. If PyTorch is already imported its bundled runtime is the one in the process (streams and device pointers
+    then interoperate with torch); otherwise use the system ROCm runtime."""
+    global HIP_RUNTIME
+    import sys
+    cands = []
+    if os.environ.get("MIJ_HIP_RUNTIME"):
+        cands.append(os.environ["MIJ_HIP_RUNTIME"])
+    if "torch" in sys.modules:
+        tl = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib")
+        cands += [os.path.join(tl, "libamdhip64.so")]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so.7"), os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            HIP_RUNTIME = c
+            return
+        except OSError:
+            continue
+    raise MiJpegError("no HIP runtime (libamdhip64) found: mi_jpeg needs ROCm and an MI355X; there is no CPU fallback")
 
 
 def load():
@@ -59,6 +86,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MiJpegError("%s is missing: build it with `python -m nvjpeg_imagecompressor_amd.build` "
                           "(there is no CPU fallback)" % LIB_PATH)
+    _bind_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, sz = C.c_void_p, C.c_size_t
     L.mij_version.restype = C.c_char_p

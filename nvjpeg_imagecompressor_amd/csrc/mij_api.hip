@@ -408,7 +408,8 @@ int mij_debug_tables(mij_encoder *e, uint8_t *dst) {
 int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream) {
   if (!d_dst || width <= 0 || rows <= 0 || pitch < (size_t)width * 3) return MIJ_ERR_INVALID_ARG;
   hipError_t he = launch_synth((uint8_t *)d_dst, width, y0, rows, pitch, bgr, (hipStream_t)stream);
-  return he == hipSuccess ? MIJ_OK : MIJ_ERR_HIP;
+  if (he != hipSuccess) return fail(nullptr, MIJ_ERR_HIP, "k_synth launch", he);
+  return MIJ_OK;
 }
 
 }  // extern "C"

@@ -844,7 +844,7 @@ __global__ void k_synth(uint8_t *dst, const int W, const int y0, const int rows,
 // Launchers. hipGetLastError() is per-thread sticky state that other HIP users in the process (e.g. a framework)
 // may have left set, so it is cleared before each launch and read right after it.
 // ---------------------------------------------------------------------------------------------------------------
-#define MIJ_LAUNCH(...) ((void)hipGetLastError(), hipLaunchKernelGGL(__VA_ARGS__))
+#define MIJ_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 template <int HS, int VS>
 static hipError_t launch_transform_t(const Geom &g, const TransformArgs &a, int interleaved, int amode, hipStream_t s) {
   constexpr int MPT = TCfg<HS, VS>::MPT;

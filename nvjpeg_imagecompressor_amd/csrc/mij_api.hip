@@ -20,7 +20,7 @@ struct mij_encoder {
   Quant *d_qt = nullptr;
   DeviceTables *d_tab = nullptr;
   uint32_t *d_hist_own = nullptr, *d_hist = nullptr;
-  int16_t *d_coef = nullptr;
+  int16_t *d_coef = nullptr, *d_dc = nullptr;
   size_t coef_count = 0;
   uint8_t *d_scratch = nullptr;
   size_t slot_bytes = 0;
@@ -125,7 +125,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   if (!e) return;
   (void)hipSetDevice(e->p.device);
   if (e->last_stream || e->issued) (void)hipStreamSynchronize(e->last_stream);
-  (void)hipFree(e->d_qt); (void)hipFree(e->d_tab); (void)hipFree(e->d_hist_own); (void)hipFree(e->d_coef);
+  (void)hipFree(e->d_qt); (void)hipFree(e->d_tab); (void)hipFree(e->d_hist_own); (void)hipFree(e->d_coef); (void)hipFree(e->d_dc);
   (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off);
   (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src);
   if (e->h_res) (void)hipHostFree(e->h_res);
@@ -185,6 +185,7 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   CRCHK(hipMemset(e->d_hist_own, 0, 4 * 257 * sizeof(uint32_t)));
   e->d_hist = e->d_hist_own;
   CRCHK(hipMalloc(&e->d_coef, e->coef_count * sizeof(int16_t)));
+  CRCHK(hipMalloc(&e->d_dc, (e->coef_count / 64) * sizeof(int16_t)));
   CRCHK(hipMalloc(&e->d_scratch, e->slot_bytes * (size_t)e->nseg));
   CRCHK(hipMalloc(&e->d_seg_bytes, (size_t)e->nseg * sizeof(uint32_t)));
   CRCHK(hipMalloc(&e->d_seg_ff, (size_t)e->nseg * sizeof(uint32_t)));
@@ -246,13 +247,11 @@ int mij_encode_transform(mij_encoder *e, const void *d_src, size_t pitch, size_t
   const bool rgb_order = fmt == MIJ_INPUT_RGB || fmt == MIJ_INPUT_RGBI;
   const int kR[3] = {19595, -11059, 32768}, kB[3] = {7471, 32768, -5329};
   for (int i = 0; i < 3; i++) { a.kA[i] = rgb_order ? kR[i] : kB[i]; a.kC[i] = rgb_order ? kB[i] : kR[i]; }
-  a.coef = e->d_coef; a.qt = e->d_qt; a.hist = e->d_hist;
+  a.coef = e->d_coef; a.qt = e->d_qt; a.hist = e->p.optimized_huffman ? e->d_hist : nullptr; a.dc = e->d_dc;
+  if (e->p.optimized_huffman) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
   HIPCHK(e, launch_transform(g, a, interleaved ? 1 : 0, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
-  if (e->p.optimized_huffman) {
-    HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
-    HIPCHK(e, launch_histogram(g, e->d_coef, e->d_hist, s));
-  }
+  if (e->p.optimized_huffman) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
   e->transformed = true;
   return MIJ_OK;
@@ -278,7 +277,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
     e->static_tables_ready = true;
   }
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
-  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, s));
+  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
   HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_res, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
@@ -301,6 +300,17 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
   if (!e->issued) return fail(e, MIJ_ERR_NOT_READY, "no encode has been issued on this handle");
   HIPCHK(e, hipSetDevice(e->p.device));
   HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  if (e->h_res->flags & 1u) {
+    // Some block needed more than a fast-path strip (768 bits): the fast encoder left those intervals marked; code them
+    // with the roomy instantiation, then redo scan + compaction.
+    hipStream_t s = e->last_stream;
+    HIPCHK(e, launch_encode(e->g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
+    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_res, s));
+    HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->nseg, e->d_out + HDR_AREA,
+                             e->capacity, e->d_res, s));
+    HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+  }
   if (e->h_res->scan_bytes > e->capacity) {
     // Output larger than the preallocated buffer (very high quality on noise): grow it and redo header + compaction.
     const size_t need = (size_t)e->h_res->scan_bytes + 65536;

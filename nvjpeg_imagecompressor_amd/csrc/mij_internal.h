@@ -17,7 +17,9 @@ namespace mij {
 // out          : uint8 [HDR_AREA + capacity]  header right-aligned in the first HDR_AREA bytes, then the scan data.
 
 constexpr int HDR_AREA = 2048;          // >= largest possible baseline header (SOI..SOS with four full DHTs = 1737 B)
-constexpr int LUT_DC_L = 0, LUT_AC_L = 16, LUT_DC_C = 272, LUT_AC_C = 288, LUT_SIZE = 544;
+constexpr int LUT_DC_L = 0, LUT_AC_L = 16, LUT_DC_C = 273, LUT_AC_C = 289, LUT_SIZE = 546;
+constexpr int LUT_AC_NONE = 256;        // extra AC entry that is always 0: "this coefficient codes nothing"
+constexpr uint32_t SEG_OVERFLOW = 0xFFFFFFFFu;  // seg_bytes marker: interval left to the slow encoder instantiation
 constexpr int MAX_BLOCK_WORDS = 53;     // ceil((16+11 + 63*(16+10)) / 32) + 1 : worst-case bits of one block
 constexpr int MAX_BLOCK_BYTES = 212;
 
@@ -56,16 +58,18 @@ struct Geom {
 struct TransformArgs {
   const uint8_t *src; size_t pitch, plane_stride;
   int kA[3], kC[3];       // colour matrix rows for the first / third stored channel (Y, Cb, Cr); G is fixed
-  int16_t *coef; const Quant *qt; uint32_t *hist;
+  int16_t *coef; const Quant *qt;
+  uint32_t *hist;         // non-null: optimised Huffman, take AC statistics (rows 1 and 3 of the 4 x 257 table)
+  int16_t *dc;            // compact DC array [strip blocks] (written when hist != null)
 };
 
 // launchers (mij_kernels.hip)
 hipError_t launch_transform(const Geom &g, const TransformArgs &a, int interleaved, hipStream_t s);
-hipError_t launch_histogram(const Geom &g, const int16_t *coef, uint32_t *hist, hipStream_t s);
+hipError_t launch_dc_stats(const Geom &g, const int16_t *dc, uint32_t *hist, hipStream_t s);
 hipError_t launch_build_tables(const Geom &g, const uint32_t *hist, int optimize, const Quant *qt, DeviceTables *tab,
                                uint8_t *out, DeviceResult *res, hipStream_t s);
 hipError_t launch_encode(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
-                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, hipStream_t s);
+                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, int slow, hipStream_t s);
 hipError_t launch_scan(const uint32_t *seg_bytes, const uint32_t *seg_ff, unsigned long long *seg_off, long long nseg,
                        DeviceResult *res, hipStream_t s);
 hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_bytes, const uint32_t *seg_bytes,

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmijpeg.so")
+LIB_PATH = os.environ.get("MIJ_LIB_PATH") or os.path.join(_HERE, "libmijpeg.so")   # override: experiment builds only
 
 MIJ_OK = 0
 MIJ_RESTART_AUTO = -1

@@ -73,8 +73,8 @@ static void make_quant(int quality, Quant &q) {
       v = std::min(255L, std::max(1L, v));
       q.q[t][i] = (uint16_t)v;
       const float d = (float)(8 * v);
-      q.recip[t][i] = 1.0f / d;
-      q.bias[t][i] = ((float)(4 * v) + 0.5f) * q.recip[t][i];
+      { float r = 1.0f / d; q.recip[t][i] = r * (1.0f + 0x1p-17f); }   // see quant_magic() in k_common.inc
+      q.bias[t][i] = 0.0f;
     }
 }
 
@@ -246,8 +246,8 @@ int mij_encode_transform(mij_encoder *e, const void *d_src, size_t pitch, size_t
   a.src = (const uint8_t *)d_src; a.pitch = pitch; a.plane_stride = plane_stride;
   const bool rgb_order = fmt == MIJ_INPUT_RGB || fmt == MIJ_INPUT_RGBI;
   const int kR[3] = {19595, -11059, 32768}, kB[3] = {7471, 32768, -5329};
-  for (int i = 0; i < 3; i++) { a.kA[i] = rgb_order ? kR[i] : kB[i]; a.kC[i] = rgb_order ? kB[i] : kR[i]; }
-  a.coef = e->d_coef; a.qt = e->d_qt; a.hist = e->p.optimized_huffman ? e->d_hist : nullptr; a.dc = e->d_dc;
+  for (int i = 0; i < 3; i++) { a.fA[i] = (rgb_order ? kR[i] : kB[i]) / 65536.0f; a.fC[i] = (rgb_order ? kB[i] : kR[i]) / 65536.0f; }
+  a.coef = e->d_coef; memcpy(a.recip, e->hq.recip, sizeof(a.recip)); a.hist = e->p.optimized_huffman ? e->d_hist : nullptr; a.dc = e->d_dc;
   if (e->p.optimized_huffman) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
   HIPCHK(e, launch_transform(g, a, interleaved ? 1 : 0, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));

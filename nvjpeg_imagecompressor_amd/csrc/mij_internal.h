@@ -57,8 +57,9 @@ struct Geom {
 
 struct TransformArgs {
   const uint8_t *src; size_t pitch, plane_stride;
-  int kA[3], kC[3];       // colour matrix rows for the first / third stored channel (Y, Cb, Cr); G is fixed
-  int16_t *coef; const Quant *qt;
+  float fA[3], fC[3];     // colour matrix rows (Y, Cb, Cr) for the first / third stored channel, times 2^-16; G is fixed
+  int16_t *coef;
+  float recip[2][64];     // quantiser reciprocals r' (see quant_magic); by value so they are always scalar loads
   uint32_t *hist;         // non-null: optimised Huffman, take AC statistics (rows 1 and 3 of the 4 x 257 table)
   int16_t *dc;            // compact DC array [strip blocks] (written when hist != null)
 };

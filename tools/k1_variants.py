@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Builds experiment variants of libmijpeg.so (compile-time switches in csrc/k_common.inc / k_transform.inc) and, with
+`run`, times the transform stage of each on the GPU through bench.py.  Usage:
+    python tools/k1_variants.py build            (here, no GPU needed)
+    python tools/k1_variants.py run [--no-optimize]   (on the GPU box)
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "variants")
+VARIANTS = {
+    "base_w3": {"MIJ_K1_WAVES": 3},
+    "base_w2": {"MIJ_K1_WAVES": 2},
+    "base_w4": {"MIJ_K1_WAVES": 4},
+    "staged_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_STAGED": 1},
+    "staged_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 1},
+    "nostore_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_NOSTORE": 1},
+    "noload_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_NOLOAD": 1},
+    "noload_nostore_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_NOLOAD": 1, "MIJ_K1_NOSTORE": 1},
+}
+
+
+def build():
+    for name, defs in VARIANTS.items():
+        d = os.path.join(OUT, name)
+        os.makedirs(d, exist_ok=True)
+        objs = []
+        for src in ("mij_kernels.hip", "mij_api.hip"):
+            obj = os.path.join(d, src.replace(".hip", ".o"))
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DMIJ_FAST_BUILD",
+                   "-Rpass-analysis=kernel-resource-usage"] + ["-D%s=%s" % kv for kv in defs.items()] + ["-c", os.path.join(CSRC, src), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode:
+                print(r.stderr[-2000:])
+                raise SystemExit(1)
+            if src == "mij_kernels.hip":
+                lines = r.stderr.splitlines()
+                for i, l in enumerate(lines):
+                    if "Function Name: _ZN3mij11k_transformILi2ELi1ELb1ELb" in l:
+                        info = [x.split("remark:")[1].split("[-R")[0].strip() for x in lines[i + 1:i + 12] if "VGPRs:" in x or "ScratchSize" in x or "Occupancy" in x]
+                        print(name, "stats" if "Lb1ELb1" in l else "nostats", info)
+            objs.append(obj)
+        subprocess.check_call(["g++", "-shared", "-o", os.path.join(d, "libmijpeg.so")] + objs)
+
+
+def run(extra):
+    for name in VARIANTS:
+        lib = os.path.join(OUT, name, "libmijpeg.so")
+        env = dict(os.environ, MIJ_LIB_PATH=lib)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-psnr"] + extra,
+                           capture_output=True, text=True, env=env)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            print("%-20s transform %.4f ms  total %.4f  crc %s" % (name, d["stage_ms"]["transform"], d["ms_per_step"], d["jpeg_crc32"]), flush=True)
+        except Exception:
+            print(name, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(sys.argv[2:])

@@ -5,9 +5,9 @@ Huffman (reference README.md:48 config), device-resident input -> device-residen
   python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
 
 A "step" is one whole encode of the image. At N > 1 the image is cut into restart-interval-aligned strips of MCU
-rows, one per rank: transform+statistics locally, ONE all-reduce of the 4x257 symbol statistics
-(RCCL), entropy coding locally, all-gather of strip sizes, gather of strip bitstreams to rank 0. Total work is fixed
-as N grows => "scaling": "strong".  Rank 0 prints ONE JSON line.
+rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
+of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes, gather of strip bitstreams to
+rank 0. Total work is fixed as N grows => "scaling": "strong".  Rank 0 prints ONE JSON line.
 """
 import argparse
 import io
@@ -42,11 +42,10 @@ def parse():
 
 
 def algorithmic_bytes_per_pixel(css, ratio):
-    """stage A reads 3 B/px and writes int16 coefficients 2(1+f); B reads them; C reads them and writes
-    the bitstream (3*ratio B/px)."""
+    """stage A reads 3 B/px and writes int16 coefficients 2(1+f); the entropy coder reads them and
+    writes the bitstream (3*ratio B/px); stuffing+compaction reads and writes the bitstream."""
     f = {"444": 2.0, "422": 1.0, "440": 1.0, "420": 0.5, "411": 0.5, "410": 0.25}[css]
-    return {"transform": 3 + 2 * (1 + f), "statistics": 2 * (1 + f), "entropy": 2 * (1 + f) + 3 * ratio,
-            "compact": 2 * 3 * ratio}
+    return {"transform": 3 + 2 * (1 + f), "entropy": 2 * (1 + f) + 3 * ratio, "compact": 2 * 3 * ratio}
 
 
 def _cpu_share():
@@ -61,62 +60,34 @@ def _cpu_share():
     return n
 
 
-def cpu_baselines(args, optimize):
+def cpu_baselines(args, optimize, restart_interval):
     """Bounded CPU sample of the same workload on the host cores: (a) the oracle C port, (b) libjpeg-turbo via Pillow.
-    One strip of the synthetic image per core, encoded concurrently (both release the GIL)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    from PIL import Image
-    # host cores this process may use (the GPU box gives a 1-GPU job a share of the node, not all of os.cpu_count())
+    One strip of the synthetic image per core; runs in a separate interpreter (tools/cpu_baseline.py) so that its
+    process pool never forks a process that holds a HIP context."""
+    import subprocess
     cores = int(os.environ.get("MIJ_BENCH_CORES", "0")) or _cpu_share()
-    rows = args.cpu_sample_rows
     css = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5}[args.css]
-    strips = [O.synth_rgb(args.width, args.height, y0=(i * rows) % max(1, args.height - rows), rows=rows) for i in range(cores)]
-    mpix = cores * rows * args.width / 1e6
-
-    def run_oracle(s):
-        return len(O.encode(s, args.quality, css, optimize, 104))
-
-    def run_turbo(s):
-        b = io.BytesIO()
-        kw = {}
-        if css <= 2:
-            Image.fromarray(s).save(b, "JPEG", quality=args.quality, subsampling=css, optimize=optimize, **kw)
-            return len(b.getvalue())
-        return 0
-
-    out = {}
-    for name, fn in (("port", run_oracle), ("turbo", run_turbo)):
-        if name == "turbo" and css > 2:
-            continue
-        best = None
-        for _ in range(2):
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                sizes = list(ex.map(fn, strips))
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        out[name] = {"value": round(mpix / best, 2), "unit": "Mpixels/s", "cores": cores,
-                     "sample": "%d strips of %dx%d synthetic RGB8 (one per core, concurrent), q%d %s %s, best of 2" %
-                               (cores, args.width, rows, args.quality, args.css, "optimised" if optimize else "fixed"),
-                     "bytes": int(sum(sizes))}
-    return out
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--width", str(args.width), "--height", str(args.height),
+           "--rows", str(args.cpu_sample_rows), "--cores", str(cores), "--quality", str(args.quality), "--css", str(css),
+           "--optimize", str(int(optimize)), "--ri", str(restart_interval)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode:
+        raise RuntimeError("cpu baseline failed: " + r.stderr[-500:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
     import nvjpeg_imagecompressor_amd as mij
+    from nvjpeg_imagecompressor_amd import sharded
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-        args.gpus = world
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -125,66 +96,25 @@ def main():
     optimize = not args.no_optimize
     W, H = args.width, args.height
 
-    # ---- strip partition (pure arithmetic, no communication) -------------------------------------------------
-    probe = mij.Encoder(W, H, args.quality, optimize, args.css, device=local_rank, strip_mcu_row0=0, strip_mcu_rows=1)
-    g0 = probe.geometry
-    probe.close()
-    mcu_rows, mcu_h = g0["mcu_rows"], g0["mcu_h"]
-    r0 = rank * mcu_rows // world
-    r1 = (rank + 1) * mcu_rows // world
-    enc = mij.Encoder(W, H, args.quality, optimize, args.css, device=local_rank, strip_mcu_row0=r0, strip_mcu_rows=r1 - r0)
+    # ---- strip partition (pure arithmetic, no communication) + this rank's pixels --------------------------------
+    enc = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, local_rank, args.fmt)
     geo = enc.geometry
     y0, rows = geo["strip_y0"], geo["strip_rows"]
-    pitch = W * 3
     d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
-    mij.synth_image_device(d_img.data_ptr(), W, y0, rows, pitch, bgr=(args.fmt == "bgr"),
-                           stream=torch.cuda.current_stream().cuda_stream)
-    d_hist = torch.zeros(4 * 257, dtype=torch.int32, device=dev)
-    enc.set_histogram_buffer(d_hist.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+    mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
+    strip = sharded.HipStripEncoder(torch, enc, d_img, args.fmt)
     enc.enable_timing(True)
     torch.cuda.synchronize()
 
-    gathered = {}
-    stage_acc = {}
+    cache, stage_acc = {}, {}
 
     def step(record):
-        s = torch.cuda.current_stream().cuda_stream
-        enc.transform(d_img.data_ptr(), pitch, args.fmt, 0, s)
-        if world > 1 and optimize:
-            dist.all_reduce(d_hist)                      # the only data-path collective before entropy coding
-        enc.entropy(s)
-        res = enc.result()                               # waits for this rank's strip; sizes now known on the host
+        out = sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
         if record:
             for k, v in enc.stage_times().items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
-        if world > 1:
-            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-            mine = torch.tensor([res["scan_bytes"]], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(sizes, mine)
-            sz = sizes.cpu().tolist()
-            view = _device_bytes(torch, res["d_buffer"] + res["scan_offset"], res["scan_bytes"], dev)
-            if rank == 0:
-                total = res["header_bytes"] + sum(sz)
-                buf = gathered.get("buf")
-                if buf is None or buf.numel() < total:
-                    buf = torch.empty(total + (total >> 3), dtype=torch.uint8, device=dev)
-                    gathered["buf"] = buf
-                hdr = _device_bytes(torch, res["d_buffer"] + res["header_offset"], res["header_bytes"] + sz[0], dev)
-                buf[:hdr.numel()].copy_(hdr)
-                ops, off = [], hdr.numel()
-                for r in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, buf[off:off + sz[r]], r))
-                    off += sz[r]
-                if ops:
-                    for w_ in dist.batch_isend_irecv(ops):
-                        w_.wait()
-                gathered["len"] = total
-            else:
-                for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, view, 0)]):
-                    w_.wait()
-        else:
-            gathered["res"] = res
-        return res
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -197,7 +127,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(True)
+        jpeg_t = step(True)
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -205,32 +135,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    mpix = W * H / 1e6
-    value = mpix / (ms_per_step / 1e3)
+    value = (W * H / 1e6) / (ms_per_step / 1e3)
 
-    # ---- rank 0: assemble, verify, report ------------------------------------------------------------------------
-    out = None
+    # ---- rank 0: verify, report ----------------------------------------------------------------------------------
     if rank == 0:
-        if world > 1:
-            jpeg = gathered["buf"][:gathered["len"]].cpu().numpy().tobytes()
-        else:
-            jpeg = enc.retrieve()
+        jpeg = jpeg_t.cpu().numpy().tobytes()
         ratio = len(jpeg) / (3.0 * W * H)
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         strip_px = rows * W
         bpp = algorithmic_bytes_per_pixel(args.css, ratio)
+        kname = {"transform": "k_transform", "entropy": "k_encode", "compact": "k_compact"}
         stage_roof = {}
-        for k in ("transform", "statistics", "entropy", "compact"):
+        for k in kname:
             if stages.get(k, 0) > 0:
                 gbs = bpp[k] * strip_px / (stages[k] * 1e-3) / 1e9
-                stage_roof[k] = {"ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"]) if stage_roof else None
-        kname = {"transform": "k_transform", "statistics": "k_histogram", "entropy": "k_encode", "compact": "k_compact"}
-        roofline = None
-        if dom:
-            roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": stage_roof[dom]["frac"], "traffic": None,
-                        "algorithmic_bytes_per_launch": int(bpp[dom] * strip_px), "avg_launch_ms": stage_roof[dom]["ms"]}
+                stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
+        dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
+        roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": stage_roof[dom]["frac"], "traffic": None,
+                    "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
+                    "note": "avg launch duration from hipEvents on the kernels' stream over the timed steps"}
         out = {
             "metric": "Mpixels/s encode (+PSNR, ratio) 8320x40000 q95 4:2:2 @1/2/4/8 GPU",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -246,24 +171,15 @@ def main():
         if not args.no_psnr:
             out["psnr_db"], out["psnr_note"] = _psnr_check(jpeg, W, H, args.fmt, d_img if world == 1 else None)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baselines(args, optimize)
+            cb = cpu_baselines(args, optimize, geo["restart_interval"])
             out["cpu_baseline"] = dict(cb["port"], kind="port", impl="oracle/jpeg_oracle.c")
             if "turbo" in cb:
-                out["cpu_libjpeg_turbo"] = dict(cb["turbo"], impl="libjpeg-turbo via Pillow")
+                out["cpu_libjpeg_turbo"] = dict(cb["turbo"], impl="libjpeg-turbo 3.1.4.1 via Pillow")
         print(json.dumps(out), flush=True)
     enc.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _device_bytes(torch, ptr, nbytes, dev):
-    """uint8 tensor view over device memory owned by libmijpeg (valid until the next encode on the handle)."""
-    class _Holder:
-        pass
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(h, device=dev)
 
 
 def _psnr_check(jpeg, W, H, fmt, d_img):

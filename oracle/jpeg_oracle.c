@@ -535,16 +535,17 @@ static void write_dht(bw_t *w, const htab_t *t, int tc_th) {
  * tables_io[0] == 0xFF... not used -- fixed tables are always Annex K.3.
  * headers: 1 = complete JFIF file (marker order SOI APP0 DQT DQT SOF0 DHTx4 [DRI] SOS ... EOI), 0 = entropy-coded
  * segment only (no markers except RSTn). */
-MJO_API int mjo_encode_coefficients(const int16_t *coef, int W, int H, int quality, int css, int optimize,
-                                    int restart_interval, int headers, uint8_t *tables_out, uint8_t **out,
-                                    size_t *out_len) {
+static int encode_worker(const int16_t *coef, int W, int H, int frame_h, int quality, int css, int optimize,
+                         int restart_interval, int headers, const uint32_t *hist_override, int rst_start,
+                         int trailing_rst, uint8_t *tables_out, uint8_t **out, size_t *out_len) {
   geom_t g;
   if (make_geom(&g, W, H, css)) return -1;
   if (restart_interval < 0 || restart_interval > 65535) return -1;
   htab_t tab[4];
   if (optimize) {
     uint32_t *hist = (uint32_t *)malloc(4 * 257 * sizeof(uint32_t));
-    mjo_histogram(coef, W, H, css, restart_interval, hist);
+    if (hist_override) memcpy(hist, hist_override, 4 * 257 * sizeof(uint32_t));
+    else mjo_histogram(coef, W, H, css, restart_interval, hist);
     for (int i = 0; i < 4; i++) {
       memset(&tab[i], 0, sizeof tab[i]);
       if (mjo_gen_optimal_table(hist + i * 257, tab[i].bits, tab[i].vals) < 0) { free(hist); return -3; }
@@ -558,7 +559,7 @@ MJO_API int mjo_encode_coefficients(const int16_t *coef, int W, int H, int quali
     for (int i = 0; i < 4; i++) { memcpy(tables_out + i * 273, tab[i].bits, 17); memcpy(tables_out + i * 273 + 17, tab[i].vals, 256); }
 
   bw_t w; memset(&w, 0, sizeof w);
-  if (headers) {
+  if (headers & 1) {
     uint16_t qt[2][64];
     mjo_quant_table(quality, 0, qt[0]); mjo_quant_table(quality, 1, qt[1]);
     bw_u16(&w, 0xFFD8);
@@ -569,7 +570,7 @@ MJO_API int mjo_encode_coefficients(const int16_t *coef, int W, int H, int quali
       bw_u16(&w, 0xFFDB); bw_u16(&w, 67); bw_byte(&w, t);
       for (int k = 0; k < 64; k++) bw_byte(&w, qt[t][k_zigzag[k]]);
     }
-    bw_u16(&w, 0xFFC0); bw_u16(&w, 17); bw_byte(&w, 8); bw_u16(&w, H); bw_u16(&w, W); bw_byte(&w, 3);
+    bw_u16(&w, 0xFFC0); bw_u16(&w, 17); bw_byte(&w, 8); bw_u16(&w, frame_h); bw_u16(&w, W); bw_byte(&w, 3);
     bw_byte(&w, 1); bw_byte(&w, (g.hs << 4) | g.vs); bw_byte(&w, 0);
     bw_byte(&w, 2); bw_byte(&w, 0x11); bw_byte(&w, 1);
     bw_byte(&w, 3); bw_byte(&w, 0x11); bw_byte(&w, 1);
@@ -580,7 +581,7 @@ MJO_API int mjo_encode_coefficients(const int16_t *coef, int W, int H, int quali
     bw_byte(&w, 0); bw_byte(&w, 63); bw_byte(&w, 0);
   }
   long nmcu = (long)g.mcux * g.mcuy;
-  int pred[3] = {0, 0, 0}, nl = g.hs * g.vs, rst = 0;
+  int pred[3] = {0, 0, 0}, nl = g.hs * g.vs, rst = rst_start & 7;
   for (long m = 0; m < nmcu; m++) {
     if (restart_interval && m && m % restart_interval == 0) {
       bw_flush(&w); bw_byte(&w, 0xFF); bw_byte(&w, 0xD0 + rst); rst = (rst + 1) & 7;
@@ -592,9 +593,29 @@ MJO_API int mjo_encode_coefficients(const int16_t *coef, int W, int H, int quali
     }
   }
   bw_flush(&w);
-  if (headers) bw_u16(&w, 0xFFD9);
+  if (trailing_rst) { bw_byte(&w, 0xFF); bw_byte(&w, 0xD0 + rst); }
+  if (headers & 2) bw_u16(&w, 0xFFD9);
   *out = w.p; *out_len = w.n;
   return 0;
+}
+
+MJO_API int mjo_encode_coefficients(const int16_t *coef, int W, int H, int quality, int css, int optimize,
+                                    int restart_interval, int headers, uint8_t *tables_out, uint8_t **out,
+                                    size_t *out_len) {
+  return encode_worker(coef, W, H, H, quality, css, optimize, restart_interval, headers ? 3 : 0, NULL, 0, 0, tables_out, out,
+                       out_len);
+}
+
+/* One strip of MCU rows of a taller frame (multi-GPU sharding): `coef` holds the strip's MCUs, the strip
+ * starts on a restart-interval boundary whose global index is rst_first, and the Huffman tables come from the
+ * statistics of the WHOLE frame (hist, 4 x 257, as all-reduced across ranks). parts: bit 0 = emit the frame header
+ * (first strip), bit 1 = emit EOI (last strip); a strip that is not the last ends with the RSTn that separates it
+ * from the next one. Concatenating the strips' outputs in order gives the file mjo_encode() writes. */
+MJO_API int mjo_encode_strip(const int16_t *coef, int W, int strip_h, int frame_h, int quality, int css, int optimize,
+                             int restart_interval, const uint32_t *hist, long rst_first, int parts, uint8_t **out,
+                             size_t *out_len) {
+  return encode_worker(coef, W, strip_h, frame_h, quality, css, optimize, restart_interval, parts & 3, optimize ? hist : NULL,
+                       (int)(rst_first & 7), (parts & 2) ? 0 : 1, NULL, out, out_len);
 }
 
 /* Whole path: what nvjpegEncodeImage + nvjpegEncodeRetrieveBitstream produce (reference .cu:280-287), as a

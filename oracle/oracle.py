@@ -171,6 +171,21 @@ def encode_coefficients(coef, W, H, quality, css, optimize, restart_interval, he
     return (data, tabs) if want_tables else data
 
 
+def encode_strip(coef, W, strip_h, frame_h, quality, css, optimize, restart_interval, hist, rst_first, first, last):
+    """Entropy-code one strip of MCU rows with the whole frame's statistics (see mjo_encode_strip)."""
+    L = lib()
+    L.mjo_encode_strip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_long, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    coef = np.ascontiguousarray(coef, np.int16)
+    hist = np.ascontiguousarray(hist, np.uint32)
+    pp, ln = C.c_void_p(), C.c_size_t()
+    rc = L.mjo_encode_strip(coef.ctypes.data, W, strip_h, frame_h, quality, css, int(optimize), restart_interval,
+                            hist.ctypes.data, rst_first, (1 if first else 0) | (2 if last else 0), C.byref(pp), C.byref(ln))
+    if rc:
+        raise RuntimeError("mjo_encode_strip rc=%d" % rc)
+    return _take(pp, ln)
+
+
 def encode(img, quality=95, css=0, optimize=True, restart_interval=0, pixfmt="rgb"):
     img, W, H, stride, fmt = _img_args(img, pixfmt)
     pp, ln = C.c_void_p(), C.c_size_t()

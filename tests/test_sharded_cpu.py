@@ -1,0 +1,97 @@
+"""world_size-2 (and 3) gloo runs of the strip-sharding orchestration (nvjpeg_imagecompressor_amd/sharded.py) on CPU.
+The HIP strip encoder needs a GPU, so the per-strip JPEG work is done here by the oracle (test infrastructure); what
+is under test is the product's partitioning, the statistics all-reduce, the size all-gather and the bitstream gather:
+the N-rank file must equal the 1-rank file byte for byte."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class OracleStripEncoder:
+    def __init__(self, O, img_strip, W, H, quality, css, optimize, ri, r0, r1, geo):
+        self.O, self.img, self.W, self.H = O, img_strip, W, H
+        self.q, self.css, self.opt, self.ri, self.r0, self.r1, self.geo = quality, css, optimize, ri, r0, r1, geo
+
+    def transform(self, stream=0):
+        self.coef = self.O.coefficients(self.img, self.q, self.css)
+        h = self.O.histogram(self.coef, self.W, self.img.shape[0], self.css, self.ri)
+        self.hist = torch.from_numpy(h.astype(np.int64).reshape(-1).astype(np.int32))
+        return self.hist
+
+    def entropy(self, stream=0):
+        first, last = self.r0 == 0, self.r1 == self.geo["mcuy"]
+        hist = self.hist.numpy().astype(np.uint32).reshape(4, 257)
+        data = self.O.encode_strip(self.coef, self.W, self.img.shape[0], self.H, self.q, self.css, self.opt, self.ri, hist,
+                                   self.r0 * self.geo["mcux"] // self.ri, first, last)
+        # every rank can produce the header (it depends on the all-reduced statistics only); strip it off here
+        hdr_len = 0
+        if first:
+            i = data.index(b"\xff\xda")
+            hdr_len = i + 2 + ((data[i + 2] << 8) | data[i + 3])
+        self.header = data[:hdr_len]
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        return buf[:hdr_len], buf[hdr_len:]
+
+
+def _worker(rank, world, port, W, H, css, optimize, ri, q, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from nvjpeg_imagecompressor_amd import sharded
+    geo = O.geometry(W, H, css)
+    unit = sharded.rows_per_restart_unit(geo["mcux"], ri)
+    r0, r1 = sharded.partition_mcu_rows(geo["mcuy"], world, rank, unit)
+    mcu_h = 8 * geo["vs"]
+    y0, y1 = r0 * mcu_h, min(r1 * mcu_h, H)
+    img = O.synth_rgb(W, H, y0, y1 - y0)
+    enc = OracleStripEncoder(O, img, W, H, q, css, optimize, ri, r0, r1, geo)
+    out = sharded.encode_step(torch, dist, enc, optimize, {})
+    if rank == 0:
+        open(out_path, "wb").write(out.numpy().tobytes())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("css,optimize,ri", [(1, True, 13), (2, True, 26), (0, False, 13), (1, True, 26)])  # last: interval spans 2 MCU rows
+def test_n_rank_file_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri):
+    W, H, q = 208, 250, 92          # H is not a multiple of the MCU height: the last strip owns the bottom edge
+    out = tmp_path / "sharded.jpg"
+    mp.spawn(_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, str(out)), nprocs=world, join=True)
+    want = oracle.encode(oracle.synth_rgb(W, H), q, css, optimize, ri)
+    got = out.read_bytes()
+    assert got == want
+
+
+def test_partition_arithmetic():
+    from nvjpeg_imagecompressor_amd import sharded
+    for rows in (1, 7, 625, 2500, 5000):
+        for world in (1, 2, 3, 4, 8):
+            for unit in (1, 2, 5):
+                cuts = [sharded.partition_mcu_rows(rows, world, r, unit) for r in range(world)]
+                assert cuts[0][0] == 0 and cuts[-1][1] == rows
+                for (a0, a1), (b0, b1) in zip(cuts[:-1], cuts[1:]):
+                    assert a1 == b0 and a0 <= a1
+                assert all(c[0] % unit == 0 for c in cuts)
+    assert sharded.rows_per_restart_unit(520, 104) == 1
+    assert sharded.rows_per_restart_unit(520, 1040) == 2
+    assert sharded.rows_per_restart_unit(26, 40) == 20      # 40 MCUs and 26 per row meet again after 20 rows

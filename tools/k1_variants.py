@@ -13,14 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
-    "base_w3": {"MIJ_K1_WAVES": 3},
-    "base_w2": {"MIJ_K1_WAVES": 2},
-    "base_w4": {"MIJ_K1_WAVES": 4},
-    "staged_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_STAGED": 1},
-    "staged_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 1},
-    "nostore_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_NOSTORE": 1},
-    "noload_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_NOLOAD": 1},
-    "noload_nostore_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_NOLOAD": 1, "MIJ_K1_NOSTORE": 1},
+    "h2_direct_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 2},
+    "h2_staged_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 1, "MIJ_HIST_COPIES": 2},
+    "h4_direct_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 4},
+    "h1_direct_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 1},
+    "h2_direct_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 2},
+    "h2_nostore_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_NOSTORE": 1, "MIJ_HIST_COPIES": 2},
 }
 
 

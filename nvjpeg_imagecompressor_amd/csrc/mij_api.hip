@@ -26,7 +26,8 @@ struct mij_encoder {
   size_t slot_bytes = 0;
   long long nseg = 0;
   uint32_t *d_seg_bytes = nullptr, *d_seg_ff = nullptr;
-  unsigned long long *d_seg_off = nullptr;
+  unsigned long long *d_seg_off = nullptr, *d_chunk_total = nullptr, *d_chunk_base = nullptr;
+  uint32_t *d_ovf = nullptr;
   uint8_t *d_out = nullptr;
   size_t capacity = 0;  // scan-data capacity (bytes after HDR_AREA)
   DeviceResult *d_res = nullptr, *h_res = nullptr;
@@ -126,7 +127,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   (void)hipSetDevice(e->p.device);
   if (e->last_stream || e->issued) (void)hipStreamSynchronize(e->last_stream);
   (void)hipFree(e->d_qt); (void)hipFree(e->d_tab); (void)hipFree(e->d_hist_own); (void)hipFree(e->d_coef); (void)hipFree(e->d_dc);
-  (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off);
+  (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off); (void)hipFree(e->d_chunk_total); (void)hipFree(e->d_chunk_base); (void)hipFree(e->d_ovf);
   (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
@@ -190,6 +191,11 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   CRCHK(hipMalloc(&e->d_seg_bytes, (size_t)e->nseg * sizeof(uint32_t)));
   CRCHK(hipMalloc(&e->d_seg_ff, (size_t)e->nseg * sizeof(uint32_t)));
   CRCHK(hipMalloc(&e->d_seg_off, (size_t)e->nseg * sizeof(unsigned long long)));
+  { const size_t nch = (size_t)((e->nseg + 1023) / 1024);
+    CRCHK(hipMalloc(&e->d_chunk_total, nch * sizeof(unsigned long long)));
+    CRCHK(hipMalloc(&e->d_chunk_base, nch * sizeof(unsigned long long))); }
+  CRCHK(hipMalloc(&e->d_ovf, sizeof(uint32_t)));
+  CRCHK(hipMemset(e->d_ovf, 0, sizeof(uint32_t)));
   CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity));
   CRCHK(hipMalloc(&e->d_res, sizeof(DeviceResult)));
   CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
@@ -279,9 +285,9 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
   HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
-  HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_res, s));
+  HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
-  HIPCHK(e, launch_compact(g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->nseg, e->d_out + HDR_AREA,
+  HIPCHK(e, launch_compact(g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
                            e->capacity, e->d_res, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[6], s));
   HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
@@ -305,8 +311,8 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
     // with the roomy instantiation, then redo scan + compaction.
     hipStream_t s = e->last_stream;
     HIPCHK(e, launch_encode(e->g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
-    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_res, s));
-    HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->nseg, e->d_out + HDR_AREA,
+    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
+    HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
                              e->capacity, e->d_res, s));
     HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipStreamSynchronize(s));
@@ -320,7 +326,7 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
     e->d_out = nb; e->capacity = need;
     hipStream_t s = e->last_stream;
     HIPCHK(e, launch_build_tables(e->g, e->d_hist, e->p.optimized_huffman ? 1 : 0, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
-    HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->nseg, e->d_out + HDR_AREA,
+    HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
                              e->capacity, e->d_res, s));
     HIPCHK(e, hipStreamSynchronize(s));
   }

@@ -72,10 +72,11 @@ hipError_t launch_build_tables(const Geom &g, const uint32_t *hist, int optimize
 hipError_t launch_encode(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
                          size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, int slow, hipStream_t s);
 hipError_t launch_scan(const uint32_t *seg_bytes, const uint32_t *seg_ff, unsigned long long *seg_off, long long nseg,
-                       DeviceResult *res, hipStream_t s);
+                       unsigned long long *chunk_total, unsigned long long *chunk_base, uint32_t *ovf_flag, DeviceResult *res,
+                       hipStream_t s);
 hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_bytes, const uint32_t *seg_bytes,
-                          const unsigned long long *seg_off, long long nseg, uint8_t *out_scan, size_t capacity,
-                          const DeviceResult *res, hipStream_t s);
+                          const unsigned long long *seg_off, const unsigned long long *chunk_base, long long nseg,
+                          uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s);
 hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
 
 }  // namespace mij

@@ -138,6 +138,34 @@ MIJ_API int mij_stage_times(mij_encoder *enc, float ms[MIJ_NUM_STAGE_TIMES]);
 MIJ_API int mij_debug_coefficients(mij_encoder *enc, int16_t *host_dst, size_t count);
 MIJ_API int mij_debug_tables(mij_encoder *enc, uint8_t *host_dst_4x273);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Decode (reference initDecodeEnv / DecodeWorker, ImageCompressorImpl.cu:67-117, 311-385). Baseline sequential 3-component
+ * files; one GPU lane per restart interval, so files written by this library (always DRI) decode in parallel and a
+ * file without restart markers decodes on a single lane (correct, slow). */
+typedef struct mij_decoder mij_decoder;
+/* initDecodeEnv (ImageCompressorImpl.cu:67-95) / destoryDecodeEnv (.cu:97-117). NULL destroy is a no-op. */
+MIJ_API int mij_decoder_create(int device, mij_decoder **out);
+MIJ_API void mij_decoder_destroy(mij_decoder *dec);
+MIJ_API const char *mij_decoder_last_error(const mij_decoder *dec);
+/* nvjpegGetImageInfo (ImageCompressorImpl.cu:335): host-side parse only; css uses the MIJ_CSS_* values. */
+MIJ_API int mij_decode_info(const uint8_t *jpeg, size_t jpeg_bytes, int *width, int *height, int *css, int *restart_interval);
+/* nvjpegJpegStreamParse + DecodeJpegHost + TransferToDevice + DecodeJpegDevice (ImageCompressorImpl.cu:362-366) with the
+ * planar->interleaved step of getCVImageOnCPU (.cu:214-221) done on the device: host JPEG bytes -> device pixels.
+ * output_format: MIJ_INPUT_BGRI / RGBI (interleaved, pitch >= 3*width) or MIJ_INPUT_BGR / RGB (planar, 3 planes at
+ * plane_stride; the reference's NVJPEG_OUTPUT_BGR, ImageCompressorImpl.cuh:69). Asynchronous on `stream` after the
+ * upload; mij_decode_sync waits and reports stream errors and the device time in ms. */
+MIJ_API int mij_decode_device(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, void *d_dst, size_t pitch,
+                              size_t plane_stride, int output_format, void *stream);
+MIJ_API int mij_decode_sync(mij_decoder *dec, float *device_ms);
+/* DecodeWorker end to end (ImageCompressorImpl.cu:311-385): host JPEG bytes -> host pixels (one D2H, already interleaved). */
+MIJ_API int mij_decode_host(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t *dst, size_t pitch,
+                            int output_format, int *width, int *height);
+
+/* Secondary ("difference map") compression, reference README.md:8 (no code in the reference; definition in SURVEY.md 8a A9):
+ * mode -1: out = clip(a - b + 128)  (residual of original a against decoded b)
+ * mode +1: out = clip(a + b - 128)  (reconstruction from decoded a and decoded residual b).  n = number of bytes. */
+MIJ_API int mij_residual_device(const void *d_a, const void *d_b, void *d_out, size_t n, int mode, void *stream);
+
 /* Bench utility: fill device memory with rows [y0, y0+rows) of the SURVEY.md 8(d) synthetic image
  * (RGB or BGR interleaved). */
 MIJ_API int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream);

@@ -22,7 +22,8 @@ EXPORTS = (
     "mij_last_error", "mij_encode_device", "mij_encode_transform", "mij_encode_entropy", "mij_histogram_device",
     "mij_set_histogram_buffer", "mij_encode_result", "mij_retrieve_bitstream", "mij_encode_host",
     "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
-    "mij_synth_image_device",
+    "mij_synth_image_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
+    "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device",
 )
 
 
@@ -110,6 +111,17 @@ def load():
     L.mij_debug_coefficients.argtypes = [vp, vp, sz]
     L.mij_debug_tables.argtypes = [vp, vp]
     L.mij_synth_image_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, sz, C.c_int, vp]
+    L.mij_decoder_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mij_decoder_destroy.argtypes = [vp]
+    L.mij_decoder_destroy.restype = None
+    L.mij_decoder_last_error.argtypes = [vp]
+    L.mij_decoder_last_error.restype = C.c_char_p
+    ip = C.POINTER(C.c_int)
+    L.mij_decode_info.argtypes = [vp, sz, ip, ip, ip, ip]
+    L.mij_decode_device.argtypes = [vp, vp, sz, vp, sz, sz, C.c_int, vp]
+    L.mij_decode_sync.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mij_decode_host.argtypes = [vp, vp, sz, vp, sz, C.c_int, ip, ip]
+    L.mij_residual_device.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     _lib = L
     return L
 

@@ -79,4 +79,22 @@ hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_byt
                           uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s);
 hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
 
+// ---- decode path (k_decode.inc) ----
+struct DecTables {                 // built on the host from the file's DHT / DQT / SOF / SOS segments
+  uint16_t look[4][512];           // 9-bit look-ahead: (length << 8) | symbol, 0 = code longer than 9 bits
+  int32_t maxcode[4][18];          // largest code of each length (-1: none)
+  int32_t valoff[4][17];           // valptr[l] - mincode[l]
+  uint8_t vals[4][256];
+  uint16_t q[2][64];               // dequantisation, natural order
+  int32_t tq[3], td[3], ta[3];
+};
+hipError_t launch_find_restarts(const uint8_t *scan, size_t n, unsigned long long *chunk_cnt, unsigned long long *chunk_base,
+                                unsigned long long *seg_pos, long long nseg, uint32_t *flag, DeviceResult *res, hipStream_t s);
+hipError_t launch_huff_decode(const Geom &g, const uint8_t *scan, size_t n, const unsigned long long *seg_pos, long long nseg,
+                              const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
+hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
+hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, uint8_t *dst, size_t pitch,
+                                 size_t plane_stride, int out_fmt, hipStream_t s);
+hipError_t launch_residual(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int sign, hipStream_t s);
+
 }  // namespace mij

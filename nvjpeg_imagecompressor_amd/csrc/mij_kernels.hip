@@ -21,6 +21,7 @@ namespace mij {
 #include "k_encode.inc"
 #include "k_finish.inc"
 #include "k_synth.inc"
+#include "k_decode.inc"
 #include "k_launch.inc"
 
 }  // namespace mij

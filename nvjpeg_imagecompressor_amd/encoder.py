@@ -118,6 +118,80 @@ class Encoder:
         return out
 
 
+class Decoder:
+    """Decoder state + device workspace (initDecodeEnv / destoryDecodeEnv, reference ImageCompressorImpl.cu:67-117)."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._L.mij_decoder_create(device, C.byref(self._h))
+        if rc:
+            msg = self._L.mij_decoder_last_error(None)
+            self._h = C.c_void_p()
+            raise MiJpegError("mij_decoder_create failed (rc=%d): %s" % (rc, msg.decode() if msg else "?"))
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self._L.mij_decoder_last_error(self._h)
+            raise MiJpegError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.mij_decoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @staticmethod
+    def info(jpeg):
+        L = _lib.load()
+        w, h, css, ri = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        buf = np.frombuffer(jpeg, np.uint8)
+        rc = L.mij_decode_info(buf.ctypes.data, len(jpeg), C.byref(w), C.byref(h), C.byref(css), C.byref(ri))
+        if rc:
+            msg = L.mij_decoder_last_error(None)
+            raise MiJpegError("mij_decode_info failed (rc=%d): %s" % (rc, msg.decode() if msg else "?"))
+        return dict(width=w.value, height=h.value, css=css.value, restart_interval=ri.value)
+
+    def decode_host(self, jpeg, fmt="bgr"):
+        """JPEG bytes -> H x W x 3 uint8 (interleaved) or 3 x H x W (planar), like DecodeWorker + getCVImageOnCPU."""
+        inf = self.info(jpeg)
+        buf = np.frombuffer(jpeg, np.uint8)
+        planar = fmt.endswith("_planar")
+        out = np.empty((3, inf["height"], inf["width"]) if planar else (inf["height"], inf["width"], 3), np.uint8)
+        w, h = C.c_int(), C.c_int()
+        self._check(self._L.mij_decode_host(self._h, buf.ctypes.data, len(jpeg), out.ctypes.data,
+                                            inf["width"] * (1 if planar else 3), _FMT[fmt], C.byref(w), C.byref(h)), "mij_decode_host")
+        return out
+
+    def decode_device(self, jpeg, d_ptr, pitch, fmt="bgr", plane_stride=0, stream=0):
+        buf = np.frombuffer(jpeg, np.uint8)
+        self._check(self._L.mij_decode_device(self._h, buf.ctypes.data, len(jpeg), C.c_void_p(d_ptr), pitch, plane_stride,
+                                              _FMT[fmt], C.c_void_p(stream)), "mij_decode_device")
+
+    def sync(self):
+        ms = C.c_float()
+        self._check(self._L.mij_decode_sync(self._h, C.byref(ms)), "mij_decode_sync")
+        return float(ms.value)
+
+
+def residual_device(d_a, d_b, d_out, nbytes, mode, stream=0):
+    """mode -1: out = clip(a - b + 128); mode +1: out = clip(a + b - 128) (difference-map compression)."""
+    L = _lib.load()
+    _lib.check(L.mij_residual_device(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out), nbytes, mode, C.c_void_p(stream)), None,
+               "mij_residual_device")
+
+
 def synth_image_device(d_ptr, width, y0, rows, pitch, bgr=False, stream=0):
     L = _lib.load()
     _lib.check(L.mij_synth_image_device(C.c_void_p(d_ptr), width, y0, rows, pitch, int(bgr), C.c_void_p(stream)),
@@ -137,6 +211,7 @@ class NvjpegCompressRunner:
         self.width, self.height, self.quality, self.optimize = width, height, quality, optimize
         self.css, self.restart_interval, self.device, self.verbose = css, restart_interval, device, verbose
         self._enc = None
+        self._dec = None
 
     def buildCompressEnv(self):
         if self._enc is None:  # a second build is a no-op (the reference leaks here)
@@ -150,10 +225,33 @@ class NvjpegCompressRunner:
             self._enc = None
 
     def buildDecodeEnv(self):
-        pass
+        if self._dec is None:
+            self._dec = Decoder(self.device)
 
     def deleteDecodeEnv(self):
-        pass
+        if self._dec is not None:
+            self._dec.close()
+            self._dec = None
+
+    def decode(self, image_path):
+        """Path of a JPEG file -> (H x W x 3 uint8 BGR, run_state); (None, 0) on failure (reference ImageCompressor.cpp:63-88)."""
+        t0 = time.perf_counter()
+        result = None
+        try:
+            try:
+                data = open(image_path, "rb").read()
+            except OSError:
+                print("Failed to open JPEG file.")
+                return None, 0
+            if self._dec is None:
+                raise MiJpegError("decode() before buildDecodeEnv()")
+            result = self._dec.decode_host(data, "bgr")
+        except MiJpegError as e:
+            print("[ERROR] Exception caught : %s" % e)
+            result = None
+        if self.verbose:
+            print("[INFO] NvjpegCompressRunner Decode Func Cost Time : %d ms" % int((time.perf_counter() - t0) * 1e3))
+        return result, (0 if result is None else 1)
 
     def compress(self, image):
         """image: H x W x 3 uint8 BGR (cv::Mat CV_8UC3). Returns (bytes, run_state)."""
@@ -186,5 +284,6 @@ class NvjpegCompressRunner:
     def __del__(self):
         try:
             self.deleteCompressEnv()
+            self.deleteDecodeEnv()
         except Exception:
             pass

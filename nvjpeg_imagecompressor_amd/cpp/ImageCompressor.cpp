@@ -11,7 +11,8 @@ class NvjpegCompressRunnerImpl {
  public:
   mij_encoder_params p{};
   mij_encoder *enc = nullptr;
-  bool verbose = true, decode_init = false;
+  mij_decoder *dec = nullptr;
+  bool verbose = true;
   std::string err;
 };
 
@@ -25,6 +26,7 @@ NvjpegCompressRunner::NvjpegCompressRunner(int width, int height, int quality, b
 
 NvjpegCompressRunner::~NvjpegCompressRunner() {
   deleteCompressEnv();
+  deleteDecodeEnv();
   const bool v = compressor->verbose;
   delete compressor;
   if (v) std::cout << "[INFO] Delete NvjpegCompressRunnerImpl Successfully ..." << std::endl;
@@ -40,8 +42,11 @@ void NvjpegCompressRunner::buildCompressEnv() {
   mij_encoder_enable_timing(compressor->enc, 1);
 }
 void NvjpegCompressRunner::deleteCompressEnv() { mij_encoder_destroy(compressor->enc); compressor->enc = nullptr; }
-void NvjpegCompressRunner::buildDecodeEnv() { compressor->decode_init = true; }
-void NvjpegCompressRunner::deleteDecodeEnv() { compressor->decode_init = false; }
+void NvjpegCompressRunner::buildDecodeEnv() {
+  if (compressor->dec) return;
+  if (mij_decoder_create(compressor->p.device, &compressor->dec) != MIJ_OK) { compressor->err = mij_decoder_last_error(nullptr); compressor->dec = nullptr; }
+}
+void NvjpegCompressRunner::deleteDecodeEnv() { mij_decoder_destroy(compressor->dec); compressor->dec = nullptr; }
 
 std::vector<unsigned char> NvjpegCompressRunner::compress(cv::Mat image, int *run_state) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -69,17 +74,42 @@ std::vector<unsigned char> NvjpegCompressRunner::compress(cv::Mat image, int *ru
 }
 
 cv::Mat NvjpegCompressRunner::decode(std::string image_path, int *run_state) {
-  // The decode path (reference ImageCompressorImpl.cu:311-385) is the next row of the scope table; until its HIP
-  // kernels land this reports failure the reference's way (empty Mat, run_state 0) rather than decoding on the CPU.
-  FILE *f = fopen(image_path.c_str(), "rb");
-  if (!f) {
+  // reference ImageCompressor.cpp:63-88 + ImageCompressorImpl.cu:311-385: open, read whole file, decode, BGR Mat.
+  cv::Mat result;
+  FILE *jpeg_file = fopen(image_path.c_str(), "rb");
+  if (!jpeg_file) {
     std::cerr << "Failed to open JPEG file." << std::endl;
-  } else {
-    fclose(f);
-    std::cerr << "[ERROR] decode(): HIP decoder not built in this version" << std::endl;
+    if (run_state) *run_state = 0;
+    return cv::Mat();
   }
-  if (run_state) *run_state = 0;
-  return cv::Mat();
+  const auto t0 = std::chrono::steady_clock::now();
+  fseek(jpeg_file, 0, SEEK_END);
+  const long sz = ftell(jpeg_file);
+  rewind(jpeg_file);
+  std::vector<unsigned char> data(sz > 0 ? (size_t)sz : 0);
+  const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), jpeg_file);
+  fclose(jpeg_file);
+  if (data.empty() || got != data.size()) {
+    std::cerr << "[INFO] Failed to read the entire JPEG data." << std::endl;
+  } else if (!compressor->dec) {
+    std::cerr << "[ERROR] decode() called before buildDecodeEnv() succeeded: " << compressor->err << std::endl;
+  } else {
+    int w = 0, h = 0;
+    if (mij_decode_info(data.data(), data.size(), &w, &h, nullptr, nullptr) == MIJ_OK) {
+      cv::Mat m(h, w, CV_8UC3);
+      if (mij_decode_host(compressor->dec, data.data(), data.size(), m.ptr<unsigned char>(0), m.step, MIJ_INPUT_BGRI, &w, &h) == MIJ_OK)
+        result = m;
+      else
+        compressor->err = mij_decoder_last_error(compressor->dec);
+    } else {
+      compressor->err = mij_decoder_last_error(nullptr);
+      std::cerr << "[ERROR] JPEG decode failed: " << compressor->err << std::endl;
+    }
+  }
+  if (run_state) *run_state = result.empty() ? 0 : 1;
+  const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  if (compressor->verbose) std::cout << "[INFO] NvjpegCompressRunner Decode Func Cost Time : " << ms << " ms" << std::endl;
+  return result;
 }
 
 void NvjpegCompressRunner::save(std::string save_path, std::vector<unsigned char> obuffer) {

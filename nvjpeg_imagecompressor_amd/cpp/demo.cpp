@@ -1,5 +1,6 @@
 // demo.cpp -- the reference demo's sequence (reference src/ImageCompressor/main.cpp:16-81) on portable inputs:
-//   new NvjpegCompressRunner -> buildCompressEnv -> compress x2 -> deleteCompressEnv -> save x2 -> delete.
+//   new NvjpegCompressRunner -> buildCompressEnv -> compress x2 -> deleteCompressEnv -> buildDecodeEnv -> save x2 ->
+//   decode x2 -> deleteDecodeEnv -> delete.
 // Inputs are binary PPM (P6) files, or a synthetic image when no path is given (no OpenCV imread in this image).
 //   demo [in1.ppm [in2.ppm]] [--css N] [--quality Q] [--out prefix]
 #include <cstdio>
@@ -66,8 +67,26 @@ int main(int argc, char *argv[]) {
   printState(compress_run_state);
   ok &= compress_run_state;
   compressor->deleteCompressEnv();
+  compressor->buildDecodeEnv();
   compressor->save(out + "_1.jpeg", obuffer1);
   compressor->save(out + "_2.jpeg", obuffer2);
+  // decode both files back (reference main.cpp:65-75) and write them as PPM (no cv::imwrite here)
+  for (int i = 1; i <= 2 && ok; i++) {
+    int decode_run_state = 0;
+    cv::Mat dec = compressor->decode(out + "_" + std::to_string(i) + ".jpeg", &decode_run_state);
+    printState(decode_run_state);
+    ok &= decode_run_state;
+    if (decode_run_state) {
+      FILE *f = fopen((out + "_" + std::to_string(i) + "_decode.ppm").c_str(), "wb");
+      if (f) {
+        fprintf(f, "P6\n%d %d\n255\n", dec.cols, dec.rows);
+        for (int y = 0; y < dec.rows; y++)
+          for (int x = 0; x < dec.cols; x++) { const unsigned char *p = dec.ptr<unsigned char>(y) + 3 * x; unsigned char rgb[3] = {p[2], p[1], p[0]}; fwrite(rgb, 1, 3, f); }
+        fclose(f);
+      }
+    }
+  }
+  compressor->deleteDecodeEnv();
   delete compressor;
   return ok ? EXIT_SUCCESS : EXIT_FAILURE;
 }

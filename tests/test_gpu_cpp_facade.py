@@ -32,12 +32,17 @@ def test_demo_sequence_matches_oracle(mij, oracle, tmp_path):
         r = subprocess.run([os.path.join(CPP, "demo"), paths[0], paths[1], "--css", str(css), "--out", out],
                            capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert r.stdout.count("[INFO] Successful.") == 2
+        assert r.stdout.count("[INFO] Successful.") == 4      # 2 compress + 2 decode
         assert "=> Compress Cost time" in r.stdout and "NvjpegCompressRunner Compress Func Cost Time" in r.stdout
         assert "Delete NvjpegCompressRunnerImpl Successfully" in r.stdout
         for i, im in enumerate(imgs):
             got = open("%s_%d.jpeg" % (out, i + 1), "rb").read()
             assert got == oracle.encode(im, 95, css, True, _dri(got))
+            ppm = open("%s_%d_decode.ppm" % (out, i + 1), "rb").read()
+            hdr = b"P6\n%d %d\n255\n" % (W, H)
+            assert ppm.startswith(hdr)
+            dec = np.frombuffer(ppm[len(hdr):], np.uint8).reshape(H, W, 3)
+            assert np.array_equal(dec, oracle.decode(got))
 
 
 def test_wrong_size_is_refused_not_overrun(mij, tmp_path):

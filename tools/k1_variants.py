@@ -13,12 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
-    "h2_direct_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 2},
-    "h2_staged_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 1, "MIJ_HIST_COPIES": 2},
-    "h4_direct_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 4},
-    "h1_direct_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 1},
-    "h2_direct_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 2},
-    "h2_nostore_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_NOSTORE": 1, "MIJ_HIST_COPIES": 2},
+    "base_w2": {"MIJ_K1_WAVES": 2},
+    "rb_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_ROWBARRIER": 1},
+    "rb_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_ROWBARRIER": 1},
+    "rb_staged_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_ROWBARRIER": 1, "MIJ_K1_STAGED": 1},
+    "rb_staged_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_ROWBARRIER": 1, "MIJ_K1_STAGED": 1},
 }
 
 
@@ -27,7 +26,7 @@ def build():
         d = os.path.join(OUT, name)
         os.makedirs(d, exist_ok=True)
         objs = []
-        for src in ("mij_kernels.hip", "mij_api.hip"):
+        for src in ("mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip"):
             obj = os.path.join(d, src.replace(".hip", ".o"))
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DMIJ_FAST_BUILD",
                    "-Rpass-analysis=kernel-resource-usage"] + ["-D%s=%s" % kv for kv in defs.items()] + ["-c", os.path.join(CSRC, src), "-o", obj]

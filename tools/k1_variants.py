@@ -13,11 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
-    "base_w2": {"MIJ_K1_WAVES": 2},
-    "rb_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_ROWBARRIER": 1},
-    "rb_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_ROWBARRIER": 1},
-    "rb_staged_w2": {"MIJ_K1_WAVES": 2, "MIJ_K1_ROWBARRIER": 1, "MIJ_K1_STAGED": 1},
-    "rb_staged_w3": {"MIJ_K1_WAVES": 3, "MIJ_K1_ROWBARRIER": 1, "MIJ_K1_STAGED": 1},
+    "pk_w3_h4": {"MIJ_K1_WAVES": 3},
+    "pk_w3_h4_noatomic": {"MIJ_K1_WAVES": 3, "MIJ_K1_STATMODE": 1},
+    "pk_w3_h4_waste": {"MIJ_K1_WAVES": 3, "MIJ_K1_STATMODE": 2},
+    "pk_w3_h8": {"MIJ_K1_WAVES": 3, "MIJ_HIST_COPIES": 8},
 }
 
 

@@ -152,8 +152,9 @@ def main():
                 stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
         dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
+        traffic, traffic_src = measured_traffic(kname[dom], args, optimize, world)
         roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": stage_roof[dom]["frac"], "traffic": None,
+                    "frac": stage_roof[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
                     "note": "avg launch duration from hipEvents on the kernels' stream over the timed steps"}
         out = {
@@ -180,6 +181,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel, args, optimize, world):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/hbm_traffic.py), or None if the passes were
+    taken on a different workload than this run. A process cannot read its own PMC counters; they come from rocprofv3."""
+    import glob
+    default = (args.width == W_IMG and args.height == H_IMG and args.css == CSS_NAME and args.quality == QUALITY and optimize and world == 1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not default or not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    k = d.get("kernels", {}).get(kernel)
+    return (k["total_bytes"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
 
 
 def _psnr_check(jpeg, W, H, fmt, d_img):

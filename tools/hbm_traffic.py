@@ -1,0 +1,48 @@
+"""HBM traffic per kernel launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+
+    tools/pmc_pass.sh fetch FETCH_SIZE && tools/pmc_pass.sh write WRITE_SIZE        # on the GPU box
+    python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_hbm_traffic.json
+
+Corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KiB; on gfx950 FETCH_SIZE tallies the
+128-B requests of wide streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+bench.py copies `total_bytes` of the dominant kernel into roofline.traffic when the workload string matches.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+SHORT = {"k_transform": "k_transform", "k_encode": "k_encode", "k_compact": "k_compact", "k_dc_stats": "k_dc_stats",
+         "k_build_tables": "k_build_tables", "k_scan_chunks": "k_scan_chunks", "k_scan_totals": "k_scan_totals"}
+
+
+def per_kernel(directory, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(directory + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            for key in SHORT:
+                if key in row["Kernel_Name"]:
+                    acc[key].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        fb = int(fetch.get(k, 0.0) * 1024 * 2)
+        wb = int(write.get(k, 0.0) * 1024)
+        kernels[k] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "launches_averaged": [nf.get(k, 0), nw.get(k, 0)]}
+    print(json.dumps({
+        "workload": "8320x40000 q95 4:2:2 optimised DRI=104, 1 GPU (bench.py defaults)",
+        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; "
+                  "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); mean per launch",
+        "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

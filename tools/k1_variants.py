@@ -13,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
-    "pk_w3_h4": {"MIJ_K1_WAVES": 3},
-    "pk_w3_h4_noatomic": {"MIJ_K1_WAVES": 3, "MIJ_K1_STATMODE": 1},
-    "pk_w3_h4_waste": {"MIJ_K1_WAVES": 3, "MIJ_K1_STATMODE": 2},
-    "pk_w3_h8": {"MIJ_K1_WAVES": 3, "MIJ_HIST_COPIES": 8},
+    "staged_h3": {},
+    "direct_h4": {"MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 4},
+    "direct_h3": {"MIJ_K1_STAGED": 0},
+    "staged_h2": {"MIJ_HIST_COPIES": 2},
 }
 
 

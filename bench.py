@@ -107,6 +107,7 @@ def main():
     enc.enable_timing(True)
     torch.cuda.synchronize()
 
+    copy_gbs = hbm_copy_ceiling(torch, dev) if rank == 0 else None
     cache, stage_acc = {}, {}
 
     def step(record):
@@ -150,6 +151,7 @@ def main():
             if stages.get(k, 0) > 0:
                 gbs = bpp[k] * strip_px / (stages[k] * 1e-3) / 1e9
                 stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "frac_of_copy_ceiling": round(gbs / copy_gbs, 4) if copy_gbs else None,
                                  "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
         dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
         traffic, traffic_src = measured_traffic(kname[dom], args, optimize, world)
@@ -167,7 +169,7 @@ def main():
                                                     "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"]},
             "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
-            "roofline": roofline, "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None, "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }
         if not args.no_psnr:
             out["psnr_db"], out["psnr_note"] = _psnr_check(jpeg, W, H, args.fmt, d_img if world == 1 else None)
@@ -181,6 +183,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_copy_ceiling(torch, dev):
+    """On-box streaming ceiling: device-to-device copy of 1 GiB, read + write bytes per second."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    del a, b
+    torch.cuda.empty_cache()
+    return 2 * n / dt / 1e9
 
 
 def measured_traffic(kernel, args, optimize, world):

@@ -122,10 +122,16 @@ MIJ_API int mij_encode_result(mij_encoder *enc, mij_result *out);
 MIJ_API int mij_retrieve_bitstream(mij_encoder *enc, uint8_t *data, size_t *length);
 
 /* CompressWorker's marshalling (ImageCompressorImpl.cu:272-277) + encode + retrieve in one call, from host memory:
- * uploads the interleaved / planar image once (no cv::split), encodes, returns a library-owned host buffer that stays
- * valid until the next call on this handle. */
+ * uploads the interleaved / planar image once (no cv::split) in ranges of MCU rows, running the transform stage of
+ * each range while the next one is on the wire, encodes, and returns a library-owned page-locked host buffer that
+ * stays valid until the next call on this handle. Fastest when `src` is page-locked (mij_host_alloc). */
 MIJ_API int mij_encode_host(mij_encoder *enc, const uint8_t *src, size_t pitch, size_t plane_stride, int input_format,
                             const uint8_t **jpeg, size_t *jpeg_bytes);
+
+/* Page-locked host memory for images handed to mij_encode_host / mij_decode_host (replaces the pageable cv::Mat data of
+ * the reference, ImageCompressorImpl.cu:273-277, whose three cudaMemcpy calls stage through the driver). */
+MIJ_API int mij_host_alloc(void **ptr, size_t bytes);
+MIJ_API void mij_host_free(void *ptr);
 
 /* Per-stage device times of the last encode in milliseconds (the reference prints one cudaEvent time,
  * ImageCompressorImpl.cu:289-291): [0] transform [1] statistics [2] table build [3] entropy code [4] scan

@@ -23,7 +23,7 @@ EXPORTS = (
     "mij_set_histogram_buffer", "mij_encode_result", "mij_retrieve_bitstream", "mij_encode_host",
     "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
     "mij_synth_image_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
-    "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device",
+    "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device", "mij_host_alloc", "mij_host_free",
 )
 
 
@@ -106,6 +106,9 @@ def load():
     L.mij_encode_result.argtypes = [vp, C.POINTER(Result)]
     L.mij_retrieve_bitstream.argtypes = [vp, vp, C.POINTER(sz)]
     L.mij_encode_host.argtypes = [vp, vp, sz, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    L.mij_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.mij_host_free.argtypes = [vp]
+    L.mij_host_free.restype = None
     L.mij_encoder_enable_timing.argtypes = [vp, C.c_int]
     L.mij_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.mij_debug_coefficients.argtypes = [vp, vp, sz]

@@ -35,6 +35,9 @@ struct mij_encoder {
   size_t d_src_bytes = 0;
   uint8_t *h_out = nullptr;
   size_t h_out_cap = 0;
+  hipStream_t s_copy = nullptr, s_work = nullptr;   // mij_encode_host: upload stream / kernel stream
+  hipEvent_t ev_chunk[2]{};                          // "chunk i has landed" (ping-pong)
+  bool host_streams = false;
   hipEvent_t ev[8]{};
   bool ev_ok = false, timing = false, timed_run = false;
   float ms[MIJ_NUM_STAGE_TIMES]{};
@@ -132,6 +135,10 @@ void mij_encoder_destroy(mij_encoder *e) {
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->ev_ok) for (auto &v : e->ev) (void)hipEventDestroy(v);
+  if (e->host_streams) {
+    (void)hipStreamDestroy(e->s_copy); (void)hipStreamDestroy(e->s_work);
+    for (auto &v : e->ev_chunk) (void)hipEventDestroy(v);
+  }
   delete e;
 }
 
@@ -237,30 +244,58 @@ int mij_histogram_device(mij_encoder *e, uint32_t **d_hist, size_t *count) {
   return MIJ_OK;
 }
 
-int mij_encode_transform(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *stream) {
-  if (!e || !d_src) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+// Stage A (+ fused statistics) over MCU rows [row0, row0 + rows) of this handle's strip. The first range of an image
+// resets the statistics, the last one adds the DC statistics; mij_encode_host streams an image through in several
+// ranges while the next one is still being uploaded.
+static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, hipStream_t s,
+                          int row0, int rows, bool first, bool last) {
   const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
-  if (!interleaved && fmt != MIJ_INPUT_RGB && fmt != MIJ_INPUT_BGR) return fail(e, MIJ_ERR_INVALID_ARG, "unknown input format");
   const Geom &g = e->g;
-  if (pitch < (size_t)g.W * (interleaved ? 3 : 1)) return fail(e, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
-  HIPCHK(e, hipSetDevice(e->p.device));
-  hipStream_t s = (hipStream_t)stream;
-  e->last_stream = s;
-  e->timed_run = e->timing;
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[0], s));
+  if (first) {
+    e->last_stream = s;
+    e->timed_run = e->timing;
+    e->transformed = false;
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[0], s));
+    if (e->p.optimized_huffman) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
+  }
   TransformArgs a{};
   a.src = (const uint8_t *)d_src; a.pitch = pitch; a.plane_stride = plane_stride;
   const bool rgb_order = fmt == MIJ_INPUT_RGB || fmt == MIJ_INPUT_RGBI;
   const int kR[3] = {19595, -11059, 32768}, kB[3] = {7471, 32768, -5329};
   for (int i = 0; i < 3; i++) { a.fA[i] = (rgb_order ? kR[i] : kB[i]) / 65536.0f; a.fC[i] = (rgb_order ? kB[i] : kR[i]) / 65536.0f; }
-  a.coef = e->d_coef; memcpy(a.recip, e->hq.recip, sizeof(a.recip)); a.hist = e->p.optimized_huffman ? e->d_hist : nullptr; a.dc = e->d_dc;
-  if (e->p.optimized_huffman) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
-  HIPCHK(e, launch_transform(g, a, interleaved ? 1 : 0, s));
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
-  if (e->p.optimized_huffman) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
-  e->transformed = true;
+  Geom sub = g;
+  const long long skip = (long long)row0 * g.mcux;
+  sub.mcu_first = g.mcu_first + skip;
+  sub.mcu_count = std::min((long long)rows * g.mcux, g.mcu_count - skip);
+  a.coef = e->d_coef + (size_t)skip * g.bpm * 64;
+  a.dc = e->d_dc + (size_t)skip * g.bpm;
+  memcpy(a.recip, e->hq.recip, sizeof(a.recip));
+  a.hist = e->p.optimized_huffman ? e->d_hist : nullptr;
+  if (sub.mcu_count > 0) HIPCHK(e, launch_transform(sub, a, interleaved ? 1 : 0, s));
+  if (last) {
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
+    if (e->p.optimized_huffman) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
+    e->transformed = true;
+  }
   return MIJ_OK;
+}
+
+static int check_input(mij_encoder *e, const void *src, size_t pitch, int fmt) {
+  if (!e || !src) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
+  if (!interleaved && fmt != MIJ_INPUT_RGB && fmt != MIJ_INPUT_BGR) return fail(e, MIJ_ERR_INVALID_ARG, "unknown input format");
+  if (pitch < (size_t)e->g.W * (interleaved ? 3 : 1)) return fail(e, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
+  return MIJ_OK;
+}
+
+static int strip_mcu_rows(const Geom &g) { return (int)((g.mcu_count + g.mcux - 1) / g.mcux); }
+
+int mij_encode_transform(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *stream) {
+  int rc = check_input(e, d_src, pitch, fmt);
+  if (rc) return rc;
+  HIPCHK(e, hipSetDevice(e->p.device));
+  return transform_rows(e, d_src, pitch, plane_stride, fmt, (hipStream_t)stream, 0, strip_mcu_rows(e->g), true, true);
 }
 
 static int run_tail(mij_encoder *e, hipStream_t s, bool tables) {
@@ -363,10 +398,29 @@ int mij_retrieve_bitstream(mij_encoder *e, uint8_t *data, size_t *length) {
   return MIJ_OK;
 }
 
+int mij_host_alloc(void **ptr, size_t bytes) {
+  if (!ptr) return MIJ_ERR_INVALID_ARG;
+  *ptr = nullptr;
+  return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? MIJ_OK : MIJ_ERR_ALLOC;
+}
+
+void mij_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
+
+// Host-resident image in, host-resident JFIF out (the reference's compress(): cv::split + 3 blocking pageable copies,
+// ImageCompressorImpl.cu:272-277, then nvjpegEncodeImage, then a D2H copy, .cu:285-287). Here the interleaved image is
+// uploaded once, in ranges of MCU rows of about HOST_CHUNK_BYTES, and stage A of each range runs while the next range
+// is on the wire; everything after stage A needs the complete statistics and runs once. With a page-locked source
+// (mij_host_alloc, or memory the caller registered) the uploads are true async DMA; with pageable memory the HIP
+// runtime stages each range itself and the overlap with stage A still holds.
+constexpr size_t HOST_CHUNK_BYTES = 32u << 20;
+
 int mij_encode_host(mij_encoder *e, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt, const uint8_t **jpeg,
                     size_t *jpeg_bytes) {
-  if (!e || !src || !jpeg || !jpeg_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  if (!jpeg || !jpeg_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  int rc = check_input(e, src, pitch, fmt);
+  if (rc) return rc;
   HIPCHK(e, hipSetDevice(e->p.device));
+  const Geom &g = e->g;
   mij_geometry geo;
   mij_encoder_geometry(e, &geo);
   const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
@@ -377,8 +431,31 @@ int mij_encode_host(mij_encoder *e, const uint8_t *src, size_t pitch, size_t pla
     HIPCHK(e, hipMalloc(&e->d_src, bytes));
     e->d_src_bytes = bytes;
   }
-  HIPCHK(e, hipMemcpy(e->d_src, src, bytes, hipMemcpyHostToDevice));  // one upload; no cv::split (reference .cu:273-277)
-  int rc = mij_encode_device(e, e->d_src, pitch, plane_stride, fmt, nullptr);
+  if (!e->host_streams) {
+    HIPCHK(e, hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking));
+    HIPCHK(e, hipStreamCreateWithFlags(&e->s_work, hipStreamNonBlocking));
+    for (auto &v : e->ev_chunk) HIPCHK(e, hipEventCreateWithFlags(&v, hipEventDisableTiming));
+    e->host_streams = true;
+  }
+  const int mcu_h = 8 * g.vs, total_rows = strip_mcu_rows(g);
+  const int per = (int)std::max<size_t>(1, HOST_CHUNK_BYTES / (pitch * (size_t)mcu_h * (interleaved ? 1 : 3)));
+  int idx = 0;
+  for (int r0 = 0; r0 < total_rows; r0 += per, idx++) {
+    const int rows = std::min(per, total_rows - r0);
+    const size_t y0 = (size_t)r0 * mcu_h;
+    const size_t y1 = std::min((size_t)geo.strip_rows, (size_t)(r0 + rows) * mcu_h);   // the last MCU row may be partial
+    if (y1 > y0) {
+      for (int pl = 0; pl < (interleaved ? 1 : 3); pl++) {
+        const size_t off = (size_t)pl * plane_stride + y0 * pitch;
+        HIPCHK(e, hipMemcpyAsync(e->d_src + off, src + off, (y1 - y0) * pitch, hipMemcpyHostToDevice, e->s_copy));
+      }
+    }
+    HIPCHK(e, hipEventRecord(e->ev_chunk[idx & 1], e->s_copy));
+    HIPCHK(e, hipStreamWaitEvent(e->s_work, e->ev_chunk[idx & 1], 0));
+    rc = transform_rows(e, e->d_src, pitch, plane_stride, fmt, e->s_work, r0, rows, r0 == 0, r0 + rows >= total_rows);
+    if (rc) return rc;
+  }
+  rc = mij_encode_entropy(e, e->s_work);
   if (rc) return rc;
   mij_result r;
   rc = mij_encode_result(e, &r);

@@ -86,7 +86,9 @@ class Encoder:
         return buf[:n.value].tobytes()
 
     # -- host path (CompressWorker, reference .cu:269-294) --------------------------------------------------------
-    def encode_host(self, img, fmt="bgr"):
+    def encode_host(self, img, fmt="bgr", as_view=False):
+        """Host image in, JFIF bytes out. `as_view=True` returns a numpy view of the library's page-locked output buffer
+        (valid until the next call on this encoder) instead of copying it into a bytes object."""
         img = np.ascontiguousarray(img, np.uint8)
         if fmt in ("rgb", "bgr"):
             pitch, plane = img.shape[1] * 3, 0
@@ -95,6 +97,8 @@ class Encoder:
         out, n = C.c_void_p(), C.c_size_t()
         _lib.check(self._L.mij_encode_host(self._h, img.ctypes.data, pitch, plane, _FMT[fmt], C.byref(out), C.byref(n)),
                    self._h, "mij_encode_host")
+        if as_view:
+            return np.ctypeslib.as_array(C.cast(out.value, C.POINTER(C.c_uint8)), shape=(n.value,))
         return C.string_at(out.value, n.value)
 
     # -- instrumentation -------------------------------------------------------------------------------------------
@@ -190,6 +194,28 @@ def residual_device(d_a, d_b, d_out, nbytes, mode, stream=0):
     L = _lib.load()
     _lib.check(L.mij_residual_device(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out), nbytes, mode, C.c_void_p(stream)), None,
                "mij_residual_device")
+
+
+class _PinnedBlock:
+    def __init__(self, L, ptr):
+        self._L, self.ptr = L, ptr
+
+    def __del__(self):
+        try:
+            self._L.mij_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (mij_host_alloc): uploads from it are direct DMA, not staged copies."""
+    L = _lib.load()
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = C.c_void_p()
+    _lib.check(L.mij_host_alloc(C.byref(ptr), max(nbytes, 1)), None, "mij_host_alloc")
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
+    buf._mij_owner = _PinnedBlock(L, ptr)    # freed when the last array over `buf` is gone
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def synth_image_device(d_ptr, width, y0, rows, pitch, bgr=False, stream=0):

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace mij;
 
@@ -19,6 +20,7 @@ struct mij_decoder {
   int16_t *d_coef = nullptr; size_t coef_cap = 0;
   uint8_t *d_planes = nullptr; size_t planes_cap = 0;
   DecTables *d_tab = nullptr;
+  DecTables *d_tabs = nullptr; size_t tabs_cap = 0;   // generic route: one table snapshot per scan
   unsigned long long *d_seg_pos = nullptr; size_t seg_cap = 0;
   unsigned long long *d_chunk_cnt = nullptr, *d_chunk_base = nullptr; size_t chunk_cap = 0;
   uint32_t *d_flags = nullptr;    // [0] scratch for the scan kernel, [1] Huffman decode errors
@@ -43,15 +45,35 @@ static const uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 
                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-struct Parsed {
-  int W = 0, H = 0, hs = 0, vs = 0, ri = 0;
-  DecTables t{};
-  bool have_tab[4] = {false, false, false, false};
-  size_t scan_off = 0;
+struct ScanInfo {
+  ScanDesc sd{};
+  size_t off = 0, len = 0;     // entropy-coded data of this scan inside the file
+  DecTables tab{};             // the Huffman tables in force when the scan starts (DHT may be re-sent between scans)
 };
 
-// Baseline sequential, 3 components, chroma 1x1, luma h x v with h in {1,2,4}, v in {1,2}: everything this project's
-// encoder writes (and what libjpeg writes for the common samplings). Anything else -> MIJ_ERR_BAD_STREAM.
+struct Parsed {
+  int W = 0, H = 0, hs = 0, vs = 0, ri = 0, ncomp = 0;
+  bool progressive = false;
+  int comp_id[3] = {0, 0, 0};
+  DecTables t{};
+  bool have_tab[4] = {false, false, false, false};
+  size_t scan_off = 0;         // first scan's data (fast path)
+  std::vector<ScanInfo> scans;
+  bool fast = false;           // one interleaved 3-component sequential scan: k_huff_decode takes it
+};
+
+// End of the entropy-coded data that starts at `i`: the next marker that is neither a stuffed FF00 nor RSTn.
+static size_t scan_end(const uint8_t *p, size_t n, size_t i) {
+  while (i + 1 < n) {
+    if (p[i] == 0xFF && p[i + 1] != 0x00 && (p[i + 1] & 0xF8) != 0xD0 && p[i + 1] != 0xFF) return i;
+    i++;
+  }
+  return n;
+}
+
+// 8-bit Huffman-coded frames: baseline / extended sequential (SOF0, SOF1) and progressive (SOF2); 1 component
+// (greyscale) or 3 components with 1x1 chroma and luma h x v, h in {1,2,4}, v in {1,2}; Huffman and quantisation table
+// ids 0..1 / 0..3. Anything else -> MIJ_ERR_BAD_STREAM with a reason.
 static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why) {
   if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) { why = "not a JPEG (no SOI)"; return MIJ_ERR_BAD_STREAM; }
   size_t i = 2;
@@ -59,31 +81,42 @@ static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why) {
     if (p[i] != 0xFF) { why = "marker expected"; return MIJ_ERR_BAD_STREAM; }
     const int m = p[i + 1];
     if (m == 0xFF) { i++; continue; }
+    if (m == 0xD9) break;                                   // EOI
+    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
     const size_t len = ((size_t)p[i + 2] << 8) | p[i + 3];
     if (len < 2 || i + 2 + len > n) { why = "truncated segment"; return MIJ_ERR_BAD_STREAM; }
     const uint8_t *s = p + i + 4;
     const size_t pl = len - 2;
     if (m == 0xDB) {
-      for (size_t k = 0; k + 65 <= pl; k += 65) {
-        if ((s[k] >> 4) != 0 || (s[k] & 15) > 1) { why = "unsupported DQT"; return MIJ_ERR_BAD_STREAM; }
+      size_t k = 0;
+      while (k + 65 <= pl) {
+        if ((s[k] >> 4) != 0 || (s[k] & 15) > 3) { why = "unsupported DQT (16-bit or id > 3)"; return MIJ_ERR_BAD_STREAM; }
         for (int z = 0; z < 64; z++) o.t.q[s[k] & 15][kZZ[z]] = s[k + 1 + z];
+        k += 65;
       }
-    } else if (m == 0xC0) {
-      if (pl < 15 || s[0] != 8 || s[5] != 3) { why = "only 8-bit 3-component frames"; return MIJ_ERR_BAD_STREAM; }
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      if (pl < 6 || s[0] != 8) { why = "only 8-bit samples"; return MIJ_ERR_BAD_STREAM; }
+      o.progressive = m == 0xC2;
+      o.ncomp = s[5];
+      if ((o.ncomp != 1 && o.ncomp != 3) || pl < 6 + 3 * (size_t)o.ncomp) { why = "only 1- or 3-component frames"; return MIJ_ERR_BAD_STREAM; }
       o.H = (s[1] << 8) | s[2]; o.W = (s[3] << 8) | s[4];
-      for (int c = 0; c < 3; c++) {
+      for (int c = 0; c < o.ncomp; c++) {
         const int hv = s[7 + 3 * c];
-        o.t.tq[c] = s[8 + 3 * c] & 1;
+        o.comp_id[c] = s[6 + 3 * c];
+        o.t.tq[c] = s[8 + 3 * c] & 3;
         if (c == 0) { o.hs = hv >> 4; o.vs = hv & 15; } else if (hv != 0x11) { why = "chroma sampling must be 1x1"; return MIJ_ERR_BAD_STREAM; }
       }
-    } else if (m >= 0xC1 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-      why = "only baseline sequential (SOF0) is handled";
+      if (o.ncomp == 1) { o.hs = o.vs = 1; o.t.tq[1] = o.t.tq[2] = o.t.tq[0]; }   // a lone component is never subsampled (A.2.2)
+      if (o.W <= 0 || o.H <= 0) { why = "empty frame"; return MIJ_ERR_BAD_STREAM; }
+      if (!((o.hs == 1 || o.hs == 2 || o.hs == 4) && (o.vs == 1 || o.vs == 2))) { why = "unsupported luma sampling"; return MIJ_ERR_BAD_STREAM; }
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      why = "only Huffman-coded sequential (SOF0/SOF1) and progressive (SOF2) frames are handled";
       return MIJ_ERR_BAD_STREAM;
     } else if (m == 0xC4) {
       size_t k = 0;
       while (k + 17 <= pl) {
         const int tc = s[k] >> 4, th = s[k] & 15;
-        if (tc > 1 || th > 1) { why = "unsupported DHT"; return MIJ_ERR_BAD_STREAM; }
+        if (tc > 1 || th > 1) { why = "unsupported DHT (table id > 1)"; return MIJ_ERR_BAD_STREAM; }
         const int t = th * 2 + tc;
         int cnt = 0;
         for (int l = 1; l <= 16; l++) cnt += s[k + l];
@@ -111,19 +144,64 @@ static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why) {
     } else if (m == 0xDD) {
       if (pl >= 2) o.ri = (s[0] << 8) | s[1];
     } else if (m == 0xDA) {
-      if (pl < 10 || s[0] != 3) { why = "only interleaved 3-component scans"; return MIJ_ERR_BAD_STREAM; }
-      for (int c = 0; c < 3; c++) { o.t.td[c] = (s[2 + 2 * c] >> 4) & 1; o.t.ta[c] = (s[2 + 2 * c] & 15) & 1; }
-      o.scan_off = i + 2 + len;
-      if (o.W <= 0 || o.H <= 0) { why = "SOS before SOF"; return MIJ_ERR_BAD_STREAM; }
-      if (!((o.hs == 1 || o.hs == 2 || o.hs == 4) && (o.vs == 1 || o.vs == 2))) { why = "unsupported luma sampling"; return MIJ_ERR_BAD_STREAM; }
-      for (int c = 0; c < 3; c++)
-        if (!o.have_tab[o.t.td[c] * 2] || !o.have_tab[o.t.ta[c] * 2 + 1]) { why = "missing Huffman table"; return MIJ_ERR_BAD_STREAM; }
-      return MIJ_OK;
+      if (o.ncomp == 0) { why = "SOS before SOF"; return MIJ_ERR_BAD_STREAM; }
+      const int ns = pl >= 1 ? s[0] : 0;
+      if (ns < 1 || ns > o.ncomp || pl < 4 + 2 * (size_t)ns) { why = "bad SOS"; return MIJ_ERR_BAD_STREAM; }
+      ScanInfo si;
+      ScanDesc &sd = si.sd;
+      sd.ncomp = ns;
+      for (int c = 0; c < ns; c++) {
+        int idx = -1;
+        for (int q = 0; q < o.ncomp; q++) if (o.comp_id[q] == s[1 + 2 * c]) idx = q;
+        if (idx < 0 || (c > 0 && idx <= sd.comp[c - 1])) { why = "bad component selector in SOS"; return MIJ_ERR_BAD_STREAM; }
+        sd.comp[c] = idx;
+        const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
+        if (td > 1 || ta > 1) { why = "Huffman table id > 1 in SOS"; return MIJ_ERR_BAD_STREAM; }
+        sd.td[c] = td * 2; sd.ta[c] = ta * 2 + 1;
+      }
+      sd.Ss = s[1 + 2 * ns]; sd.Se = s[2 + 2 * ns];
+      const int Ah = s[3 + 2 * ns] >> 4;
+      sd.Al = s[3 + 2 * ns] & 15;
+      if (o.progressive) {
+        if (sd.Ss > sd.Se || sd.Se > 63 || sd.Al > 13 || (sd.Ss == 0 && sd.Se != 0) || (sd.Ss > 0 && ns != 1) || (Ah != 0 && Ah != sd.Al + 1)) {
+          why = "invalid progressive scan parameters"; return MIJ_ERR_BAD_STREAM;
+        }
+        sd.kind = sd.Ss == 0 ? (Ah == 0 ? 1 : 2) : (Ah == 0 ? 3 : 4);
+      } else {
+        if (sd.Ss != 0 || sd.Se != 63 || Ah != 0 || sd.Al != 0) { why = "invalid sequential scan parameters"; return MIJ_ERR_BAD_STREAM; }
+        sd.kind = 0;
+      }
+      for (int c = 0; c < ns; c++) {
+        if ((sd.kind <= 1) && !o.have_tab[sd.td[c]]) { why = "missing DC Huffman table"; return MIJ_ERR_BAD_STREAM; }
+        if ((sd.kind == 0 || sd.kind >= 3) && !o.have_tab[sd.ta[c]]) { why = "missing AC Huffman table"; return MIJ_ERR_BAD_STREAM; }
+      }
+      const int mcux = (o.W + 8 * o.hs - 1) / (8 * o.hs), mcuy = (o.H + 8 * o.vs - 1) / (8 * o.vs);
+      if (ns > 1) {
+        if (ns != o.ncomp) { why = "partially interleaved scans are not handled"; return MIJ_ERR_BAD_STREAM; }
+        sd.bw = mcux; sd.bh = mcuy; sd.nmcu = (long long)mcux * mcuy;
+      } else if (o.ncomp == 1) {
+        sd.bw = (o.W + 7) / 8; sd.bh = (o.H + 7) / 8; sd.nmcu = (long long)sd.bw * sd.bh;
+      } else {
+        const int cw = sd.comp[0] == 0 ? o.W : (o.W + o.hs - 1) / o.hs, ch = sd.comp[0] == 0 ? o.H : (o.H + o.vs - 1) / o.vs;
+        sd.bw = (cw + 7) / 8; sd.bh = (ch + 7) / 8; sd.nmcu = (long long)sd.bw * sd.bh;
+      }
+      sd.ri = o.ri;
+      si.off = i + 2 + len;
+      si.len = scan_end(p, n, si.off) - si.off;
+      for (int c = 0; c < 3; c++) { o.t.td[c] = c < ns ? sd.td[c] / 2 : 0; o.t.ta[c] = c < ns ? sd.ta[c] / 2 : 0; }
+      si.tab = o.t;
+      if (o.scans.empty()) o.scan_off = si.off;
+      o.scans.push_back(si);
+      i = si.off + si.len;
+      continue;
     }
     i += 2 + len;
   }
-  why = "no SOS";
-  return MIJ_ERR_BAD_STREAM;
+  if (o.scans.empty()) { why = "no SOS"; return MIJ_ERR_BAD_STREAM; }
+  // later DQT segments may follow earlier scans: every scan's table snapshot gets the final quantisation tables
+  for (auto &sc : o.scans) { memcpy(sc.tab.q, o.t.q, sizeof o.t.q); memcpy(sc.tab.tq, o.t.tq, sizeof o.t.tq); }
+  o.fast = !o.progressive && o.scans.size() == 1 && o.ncomp == 3 && o.scans[0].sd.ncomp == 3;
+  return MIJ_OK;
 }
 
 static int css_of(int hs, int vs) {
@@ -168,7 +246,7 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_tabs);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   delete d;
 }
@@ -213,13 +291,23 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   g.mcux = (g.W + 8 * g.hs - 1) / (8 * g.hs); g.mcuy = (g.H + 8 * g.vs - 1) / (8 * g.vs);
   g.mcu_first = 0; g.mcu_count = (long long)g.mcux * g.mcuy; g.last_strip = 1;
   g.ri = ps.ri > 0 ? ps.ri : (int)std::min<long long>(g.mcu_count, 0x7FFFFFFF);   // no DRI: one interval = one lane (slow)
-  const long long nseg = (g.mcu_count + g.ri - 1) / g.ri;
-  const size_t scan_len = jpeg_bytes - ps.scan_off;
-  const size_t nchunks = (scan_len + 16383) / 16384 + 1;
   const size_t ncoef = (size_t)g.mcu_count * g.bpm * 64;
   const size_t ysz = (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8, csz = (size_t)g.mcux * 8 * g.mcuy * 8;
-  if ((rc = ensure(d, d->d_scan, d->scan_cap, scan_len + 16)) || (rc = ensure(d, d->d_coef, d->coef_cap, ncoef)) ||
-      (rc = ensure(d, d->d_planes, d->planes_cap, ysz + 2 * csz)) || (rc = ensure(d, d->d_seg_pos, d->seg_cap, (size_t)nseg + 1)))
+  // entropy-coded bytes of all scans, from the first scan's data to the end of the last one's
+  const size_t data_off = ps.scans.front().off;
+  const size_t scan_len = ps.fast ? jpeg_bytes - data_off : ps.scans.back().off + ps.scans.back().len - data_off;
+  long long max_seg = 1;
+  size_t max_len = 0;
+  for (const auto &sc : ps.scans) {
+    const long long ns = sc.sd.ri > 0 ? (sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri : 1;
+    max_seg = std::max(max_seg, ns);
+    max_len = std::max(max_len, sc.len);
+  }
+  if (ps.fast) { max_seg = (g.mcu_count + g.ri - 1) / g.ri; max_len = scan_len; }
+  const size_t nchunks = (max_len + 16383) / 16384 + 1;
+  if ((rc = ensure(d, d->d_scan, d->scan_cap, scan_len + 64 /* BitReader window slack */)) || (rc = ensure(d, d->d_coef, d->coef_cap, ncoef)) ||
+      (rc = ensure(d, d->d_planes, d->planes_cap, ysz + 2 * csz)) || (rc = ensure(d, d->d_seg_pos, d->seg_cap, (size_t)max_seg + 1)) ||
+      (rc = ensure(d, d->d_tabs, d->tabs_cap, ps.scans.size())))
     return rc;
   if (nchunks > d->chunk_cap) {
     (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); d->chunk_cap = 0;
@@ -229,14 +317,33 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   }
   DHIP(d, hipEventRecord(d->ev0, s));
   // nvjpegDecodeJpegTransferToDevice (reference .cu:365): entropy-coded data + tables
-  DHIP(d, hipMemcpyAsync(d->d_scan, jpeg + ps.scan_off, scan_len, hipMemcpyHostToDevice, s));
-  DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
+  DHIP(d, hipMemcpyAsync(d->d_scan, jpeg + data_off, scan_len, hipMemcpyHostToDevice, s));
   DHIP(d, hipMemsetAsync(d->d_flags, 0, 2 * sizeof(uint32_t), s));
-  DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
-  DHIP(d, launch_find_restarts(d->d_scan, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, nseg, d->d_flags, d->d_res, s));
-  DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, nseg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+  const DecTables *d_final = d->d_tab;
+  if (ps.fast) {
+    DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
+    DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
+    DHIP(d, launch_find_restarts(d->d_scan, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
+    DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+  } else {
+    // generic route (k_decode_scans.inc): scans in file order into a zeroed coefficient buffer
+    std::vector<DecTables> tabs(ps.scans.size());
+    for (size_t i = 0; i < ps.scans.size(); i++) tabs[i] = ps.scans[i].tab;
+    DHIP(d, hipMemcpyAsync(d->d_tabs, tabs.data(), tabs.size() * sizeof(DecTables), hipMemcpyHostToDevice, s));
+    DHIP(d, hipMemsetAsync(d->d_coef, 0, ncoef * sizeof(int16_t), s));
+    DHIP(d, hipStreamSynchronize(s));   // `tabs` lives on this stack frame
+    for (size_t i = 0; i < ps.scans.size(); i++) {
+      const ScanInfo &sc = ps.scans[i];
+      const uint8_t *base = d->d_scan + (sc.off - data_off);
+      const long long ns = sc.sd.ri > 0 ? (sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri : 1;
+      if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, ns, d->d_flags, d->d_res, s));
+      else DHIP(d, hipMemsetAsync(d->d_seg_pos, 0, sizeof(unsigned long long), s));
+      DHIP(d, launch_scan_decode(g, sc.sd, base, sc.len, d->d_seg_pos, ns, d->d_tabs + i, d->d_coef, d->d_flags + 1, s));
+    }
+    d_final = d->d_tabs + (ps.scans.size() - 1);
+  }
   uint8_t *py = d->d_planes, *pcb = py + ysz, *pcr = pcb + csz;
-  DHIP(d, launch_idct(g, d->d_coef, d->d_tab, py, pcb, pcr, s));
+  DHIP(d, launch_idct(g, d->d_coef, d_final, py, pcb, pcr, s));
   DHIP(d, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, pitch, plane_stride, output_format, s));
   DHIP(d, hipEventRecord(d->ev1, s));
   d->issued = true;

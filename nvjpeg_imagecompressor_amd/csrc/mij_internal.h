@@ -85,13 +85,27 @@ struct DecTables {                 // built on the host from the file's DHT / DQ
   int32_t maxcode[4][18];          // largest code of each length (-1: none)
   int32_t valoff[4][17];           // valptr[l] - mincode[l]
   uint8_t vals[4][256];
-  uint16_t q[2][64];               // dequantisation, natural order
+  uint16_t q[4][64];               // dequantisation, natural order
   int32_t tq[3], td[3], ta[3];
 };
 hipError_t launch_find_restarts(const uint8_t *scan, size_t n, unsigned long long *chunk_cnt, unsigned long long *chunk_base,
                                 unsigned long long *seg_pos, long long nseg, uint32_t *flag, DeviceResult *res, hipStream_t s);
 hipError_t launch_huff_decode(const Geom &g, const uint8_t *scan, size_t n, const unsigned long long *seg_pos, long long nseg,
                               const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
+// One scan of a file that the generic scan decoder handles (k_decode_scans.inc).
+struct ScanDesc {
+  int kind;            // 0 sequential (DC + AC), 1 DC first, 2 DC refinement, 3 AC first, 4 AC refinement
+  int ncomp;           // components in this scan; > 1 means MCU-interleaved
+  int comp[3];         // 0 = Y, 1 = Cb, 2 = Cr
+  int td[3], ta[3];    // table slots in DecTables (id * 2 for DC, id * 2 + 1 for AC)
+  int Ss, Se, Al;
+  int ri;              // MCUs (of this scan) per restart interval; 0 = no restart markers
+  int bw, bh;          // single-component scan: that component's block grid (T.81 A.2.2: ceil(samples / 8))
+  long long nmcu;      // MCUs of this scan
+};
+
+hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, const unsigned long long *seg_pos,
+                              long long nseg, const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
 hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
 hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, uint8_t *dst, size_t pitch,
                                  size_t plane_stride, int out_fmt, hipStream_t s);

@@ -22,6 +22,7 @@ namespace mij {
 #include "k_finish.inc"
 #include "k_synth.inc"
 #include "k_decode.inc"
+#include "k_decode_scans.inc"
 #include "k_launch.inc"
 
 }  // namespace mij

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,7 +24,9 @@ struct mij_decoder {
   DecTables *d_tabs = nullptr; size_t tabs_cap = 0;   // generic route: one table snapshot per scan
   unsigned long long *d_seg_pos = nullptr; size_t seg_cap = 0;
   unsigned long long *d_chunk_cnt = nullptr, *d_chunk_base = nullptr; size_t chunk_cap = 0;
-  uint32_t *d_flags = nullptr;    // [0] scratch for the scan kernel, [1] Huffman decode errors
+  uint32_t *d_flags = nullptr;    // [0] scratch for the scan kernel, [1] Huffman decode errors, [2] "a synchronisation pass changed a state"
+  uint8_t *d_par_ws = nullptr; size_t par_ws_cap = 0;   // workspace of the parallel baseline decoder
+  int sync_passes = 0;
   DeviceResult *d_res = nullptr;
   uint8_t *d_out = nullptr; size_t out_cap = 0;
   hipStream_t last_stream = nullptr;
@@ -246,7 +249,7 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_tabs);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   delete d;
 }
@@ -262,8 +265,8 @@ int mij_decoder_create(int device, mij_decoder **out) {
   if (!d) return dfail(nullptr, MIJ_ERR_ALLOC, "out of host memory");
   d->device = device;
   hipError_t he;
-  if ((he = hipMalloc(&d->d_tab, sizeof(DecTables))) != hipSuccess || (he = hipMalloc(&d->d_flags, 2 * sizeof(uint32_t))) != hipSuccess ||
-      (he = hipMalloc(&d->d_res, sizeof(DeviceResult))) != hipSuccess || (he = hipMemset(d->d_flags, 0, 2 * sizeof(uint32_t))) != hipSuccess ||
+  if ((he = hipMalloc(&d->d_tab, sizeof(DecTables))) != hipSuccess || (he = hipMalloc(&d->d_flags, 4 * sizeof(uint32_t))) != hipSuccess ||
+      (he = hipMalloc(&d->d_res, sizeof(DeviceResult))) != hipSuccess || (he = hipMemset(d->d_flags, 0, 4 * sizeof(uint32_t))) != hipSuccess ||
       (he = hipEventCreate(&d->ev0)) != hipSuccess || (he = hipEventCreate(&d->ev1)) != hipSuccess) {
     mij_decoder_destroy(d);
     return dfail(nullptr, MIJ_ERR_HIP, "decoder setup", he);
@@ -324,7 +327,18 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
     DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
     DHIP(d, launch_find_restarts(d->d_scan, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
-    DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+    static const bool lanes_only = getenv("MIJ_DECODE_LANES") != nullptr;   // A/B switch: one lane per restart interval (k_huff_decode)
+    if (lanes_only) {
+      DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+    } else {
+      // subsequence-parallel decode (k_decode_par.inc); its synchronisation passes are checked from the host, so this
+      // call waits for them (the IDCT / colour kernels that follow are still asynchronous)
+      if ((rc = ensure(d, d->d_par_ws, d->par_ws_cap, par_workspace_bytes(scan_len, max_seg)))) return rc;
+      DHIP(d, launch_par_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_par_ws, d->d_flags + 2, d->d_flags + 1,
+                                &d->sync_passes, s));
+      if (d->sync_passes < 0)   // the states did not settle within 64 passes (adversarial data): exact lane-per-interval decode
+        DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+    }
   } else {
     // generic route (k_decode_scans.inc): scans in file order into a zeroed coefficient buffer
     std::vector<DecTables> tabs(ps.scans.size());

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <utility>
 
 namespace mij {
 
@@ -106,6 +107,10 @@ struct ScanDesc {
 
 hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, const unsigned long long *seg_pos,
                               long long nseg, const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
+// Parallel (self-synchronising) decode of a baseline interleaved scan. `ws` is a workspace of par_workspace_bytes().
+size_t par_workspace_bytes(size_t scan_len, long long nseg);
+hipError_t launch_par_decode(const Geom &g, const uint8_t *scan, size_t n, const unsigned long long *seg_pos, long long nseg,
+                             const DecTables *tab, int16_t *coef, void *ws, uint32_t *changed, uint32_t *err_flag, int *passes, hipStream_t s);
 hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
 hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, uint8_t *dst, size_t pitch,
                                  size_t plane_stride, int out_fmt, hipStream_t s);

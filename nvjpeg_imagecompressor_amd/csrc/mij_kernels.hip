@@ -23,6 +23,7 @@ namespace mij {
 #include "k_synth.inc"
 #include "k_decode.inc"
 #include "k_decode_scans.inc"
+#include "k_decode_par.inc"
 #include "k_launch.inc"
 
 }  // namespace mij

@@ -190,7 +190,9 @@ static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why) {
       }
       sd.ri = o.ri;
       si.off = i + 2 + len;
-      si.len = scan_end(p, n, si.off) - si.off;
+      // A sequential scan that carries every component is the only scan of its frame: its data runs to the end of the
+      // file and need not be walked on the CPU (204 MB at the full size); anything else may be followed by more scans.
+      si.len = (!o.progressive && ns == o.ncomp) ? n - si.off : scan_end(p, n, si.off) - si.off;
       for (int c = 0; c < 3; c++) { o.t.td[c] = c < ns ? sd.td[c] / 2 : 0; o.t.ta[c] = c < ns ? sd.ta[c] / 2 : 0; }
       si.tab = o.t;
       if (o.scans.empty()) o.scan_off = si.off;

@@ -145,9 +145,15 @@ MIJ_API int mij_debug_coefficients(mij_encoder *enc, int16_t *host_dst, size_t c
 MIJ_API int mij_debug_tables(mij_encoder *enc, uint8_t *host_dst_4x273);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Decode (reference initDecodeEnv / DecodeWorker, ImageCompressorImpl.cu:67-117, 311-385). Baseline sequential 3-component
- * files; one GPU lane per restart interval, so files written by this library (always DRI) decode in parallel and a
- * file without restart markers decodes on a single lane (correct, slow). */
+ * Decode (reference initDecodeEnv / DecodeWorker, ImageCompressorImpl.cu:67-117, 311-385). Accepted: 8-bit Huffman-coded
+ * JPEG, baseline / extended sequential (SOF0, SOF1) and progressive (SOF2, the mode the reference's encoder writes),
+ * 3 components (1x1 chroma; luma 1x1, 2x1, 2x2, 1x2, 4x1, 4x2) or greyscale, with or without restart markers.
+ *  - One interleaved sequential scan (this library's output, camera files): decoded in parallel -- every restart interval
+ *    is further cut into 1-KiB subsequences that are decoded speculatively and synchronised (k_decode_par.inc), so a file
+ *    WITHOUT restart markers is as fast as one with them.
+ *  - Progressive and multi-scan files: exact, one GPU lane per restart interval of each scan (k_decode_scans.inc);
+ *    without restart markers that is one lane per scan -- fine for pictures, slow for hundreds of megapixels.
+ * Pixels are identical to libjpeg-turbo's (islow IDCT, fancy upsampling). */
 typedef struct mij_decoder mij_decoder;
 /* initDecodeEnv (ImageCompressorImpl.cu:67-95) / destoryDecodeEnv (.cu:97-117). NULL destroy is a no-op. */
 MIJ_API int mij_decoder_create(int device, mij_decoder **out);
@@ -158,8 +164,9 @@ MIJ_API int mij_decode_info(const uint8_t *jpeg, size_t jpeg_bytes, int *width, 
 /* nvjpegJpegStreamParse + DecodeJpegHost + TransferToDevice + DecodeJpegDevice (ImageCompressorImpl.cu:362-366) with the
  * planar->interleaved step of getCVImageOnCPU (.cu:214-221) done on the device: host JPEG bytes -> device pixels.
  * output_format: MIJ_INPUT_BGRI / RGBI (interleaved, pitch >= 3*width) or MIJ_INPUT_BGR / RGB (planar, 3 planes at
- * plane_stride; the reference's NVJPEG_OUTPUT_BGR, ImageCompressorImpl.cuh:69). Asynchronous on `stream` after the
- * upload; mij_decode_sync waits and reports stream errors and the device time in ms. */
+ * plane_stride; the reference's NVJPEG_OUTPUT_BGR, ImageCompressorImpl.cuh:69). Returns once the entropy decoding is
+ * synchronised (its passes are counted from the host); the remaining kernels are asynchronous on `stream`.
+ * mij_decode_sync waits and reports stream errors and the device time in ms. */
 MIJ_API int mij_decode_device(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, void *d_dst, size_t pitch,
                               size_t plane_stride, int output_format, void *stream);
 MIJ_API int mij_decode_sync(mij_decoder *dec, float *device_ms);

@@ -634,3 +634,222 @@ MJO_API int mjo_encode(const uint8_t *src, int W, int H, size_t stride, int pixf
 }
 
 MJO_API void mjo_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------------
+ * Progressive mode (SOF2) -- the mode the reference's encoder is configured for
+ * (nvjpegEncoderParamsSetEncoding(NVJPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN), reference ImageCompressorImpl.cu:28).
+ * nvJPEG's scan script is not public; this restates what libjpeg writes for a 3-component YCbCr image:
+ * the scan script of jpeg_simple_progression (jcparam.c) and the entropy coding procedures of T.81 G.1.2 as
+ * implemented by jcphuff.c (EOB runs, correction bits buffered behind an EOB run, the 0x7FFF / 937-bit flush
+ * rules), with an optimal Huffman table per scan (progressive libjpeg always optimises) and the marker order of
+ * jcmarker.c (DHT for the tables a scan uses, DRI before the first SOS, SOS). Pinned byte-for-byte against
+ * libjpeg-turbo 3.1.4.1 (Pillow, progressive=True) in tests/test_oracle_pin.py.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int ncomp, comp[3], Ss, Se, Ah, Al; } pscan_t;
+static const pscan_t k_simple_progression[10] = {
+    {3, {0, 1, 2}, 0, 0, 0, 1},                                       /* initial DC scan */
+    {1, {0, 0, 0}, 1, 5, 0, 2},                                       /* some luma AC in a hurry */
+    {1, {2, 0, 0}, 1, 63, 0, 1}, {1, {1, 0, 0}, 1, 63, 0, 1},         /* chroma AC: Cr, then Cb */
+    {1, {0, 0, 0}, 6, 63, 0, 2},                                      /* rest of the luma spectrum */
+    {1, {0, 0, 0}, 1, 63, 2, 1},                                      /* next bit of luma AC */
+    {3, {0, 1, 2}, 0, 0, 1, 0},                                       /* last DC bit */
+    {1, {2, 0, 0}, 1, 63, 1, 0}, {1, {1, 0, 0}, 1, 63, 1, 0},         /* last chroma AC bit */
+    {1, {0, 0, 0}, 1, 63, 1, 0}};                                     /* last luma AC bit */
+
+#define MJO_MAX_CORR_BITS 1000
+typedef struct {
+  bw_t *w;                 /* NULL while gathering statistics */
+  uint32_t *count[2];      /* statistics: [table id 0/1][257] */
+  const htab_t *tab[2];    /* tables of this scan, by table id */
+  unsigned EOBRUN, BE;
+  uint8_t corr[MJO_MAX_CORR_BITS];
+  int ac_tbl;              /* table id of the (single) component of an AC scan */
+} penc_t;
+
+static void pe_symbol(penc_t *e, int tbl, int sym) {
+  if (!e->w) e->count[tbl][sym]++;
+  else bw_bits(e->w, e->tab[tbl]->code[sym], e->tab[tbl]->len[sym]);
+}
+static void pe_bits(penc_t *e, unsigned v, int n) { if (e->w && n) bw_bits(e->w, v, n); }
+static void pe_eobrun(penc_t *e) {
+  if (e->EOBRUN > 0) {
+    int nb = 0; unsigned t = e->EOBRUN; while (t > 1) { nb++; t >>= 1; }
+    pe_symbol(e, e->ac_tbl, nb << 4);
+    if (nb) pe_bits(e, e->EOBRUN, nb);
+    e->EOBRUN = 0;
+    for (unsigned i = 0; i < e->BE; i++) pe_bits(e, e->corr[i], 1);
+    e->BE = 0;
+  }
+}
+
+static void pe_block(penc_t *e, const pscan_t *sc, int ci, const int16_t *blk, int *last_dc) {
+  const int Al = sc->Al, tbl = ci ? 1 : 0;
+  if (sc->Ss == 0) {
+    if (sc->Ah == 0) {                      /* DC first: the point-transformed value, difference coded as in F.1.2.1 */
+      int v = blk[0] >> Al;                 /* arithmetic shift */
+      int t = v - last_dc[ci], t2 = t; last_dc[ci] = v;
+      if (t < 0) { t = -t; t2--; }
+      int n = nbits_of(t);
+      pe_symbol(e, tbl, n);
+      if (n) pe_bits(e, (unsigned)t2, n);
+    } else {
+      pe_bits(e, (unsigned)(blk[0] >> Al) & 1u, 1);
+    }
+    return;
+  }
+  if (sc->Ah == 0) {                        /* AC first (figure G.3) */
+    int r = 0;
+    for (int k = sc->Ss; k <= sc->Se; k++) {
+      int t = blk[k], t2;
+      if (t == 0) { r++; continue; }
+      if (t < 0) { t = -t; t >>= Al; t2 = ~t; } else { t >>= Al; t2 = t; }
+      if (t == 0) { r++; continue; }
+      if (e->EOBRUN > 0) pe_eobrun(e);
+      while (r > 15) { pe_symbol(e, tbl, 0xF0); r -= 16; }
+      int n = nbits_of(t);
+      pe_symbol(e, tbl, (r << 4) + n);
+      pe_bits(e, (unsigned)t2, n);
+      r = 0;
+    }
+    if (r > 0) { e->EOBRUN++; if (e->EOBRUN == 0x7FFF) pe_eobrun(e); }
+    return;
+  }
+  /* AC refinement (figures G.5 - G.7) */
+  int absv[64], EOB = 0;
+  for (int k = sc->Ss; k <= sc->Se; k++) {
+    int t = blk[k]; if (t < 0) t = -t;
+    t >>= Al; absv[k] = t;
+    if (t == 1) EOB = k;                    /* last coefficient that becomes non-zero in this scan */
+  }
+  int r = 0;
+  unsigned BR = 0;
+  uint8_t *BRbuf = e->corr + e->BE;         /* appended after the bits already buffered behind the EOB run */
+  for (int k = sc->Ss; k <= sc->Se; k++) {
+    int t = absv[k];
+    if (t == 0) { r++; continue; }
+    while (r > 15 && k <= EOB) {
+      pe_eobrun(e);
+      pe_symbol(e, tbl, 0xF0); r -= 16;
+      for (unsigned i = 0; i < BR; i++) pe_bits(e, BRbuf[i], 1);
+      BRbuf = e->corr; BR = 0;
+    }
+    if (t > 1) { BRbuf[BR++] = (uint8_t)(t & 1); continue; }     /* already non-zero: one correction bit */
+    pe_eobrun(e);
+    pe_symbol(e, tbl, (r << 4) + 1);
+    pe_bits(e, blk[k] < 0 ? 0u : 1u, 1);
+    for (unsigned i = 0; i < BR; i++) pe_bits(e, BRbuf[i], 1);
+    BRbuf = e->corr; BR = 0; r = 0;
+  }
+  if (r > 0 || BR > 0) {
+    e->EOBRUN++; e->BE += BR;
+    if (e->EOBRUN == 0x7FFF || e->BE > (MJO_MAX_CORR_BITS - 64 + 1)) pe_eobrun(e);
+  }
+}
+
+/* One pass over a scan: statistics when e->w == NULL, output otherwise. */
+static void pe_scan(penc_t *e, const pscan_t *sc, const geom_t *g, int W, int H, const int16_t *coef, int restart_interval) {
+  const int nl = g->hs * g->vs;
+  int last_dc[3] = {0, 0, 0}, rst = 0;
+  e->EOBRUN = 0; e->BE = 0;
+  e->ac_tbl = sc->comp[0] ? 1 : 0;
+  long nmcu; int bw = 0;
+  if (sc->ncomp > 1) nmcu = (long)g->mcux * g->mcuy;
+  else {
+    const int c = sc->comp[0];
+    const int cw = c == 0 ? W : ceil_div(W, g->hs), ch = c == 0 ? H : ceil_div(H, g->vs);
+    bw = ceil_div(cw, 8);
+    nmcu = (long)bw * ceil_div(ch, 8);
+  }
+  for (long m = 0; m < nmcu; m++) {
+    if (restart_interval && m && m % restart_interval == 0) {
+      pe_eobrun(e);
+      if (e->w) { bw_flush(e->w); bw_byte(e->w, 0xFF); bw_byte(e->w, 0xD0 + rst); }
+      rst = (rst + 1) & 7;
+      last_dc[0] = last_dc[1] = last_dc[2] = 0;
+      e->EOBRUN = 0; e->BE = 0;
+    }
+    if (sc->ncomp > 1) {
+      for (int b = 0; b < g->bpm; b++) pe_block(e, sc, b < nl ? 0 : b - nl + 1, coef + ((size_t)m * g->bpm + b) * 64, last_dc);
+    } else {
+      const int c = sc->comp[0], bx = (int)(m % bw), by = (int)(m / bw);
+      size_t slot = c == 0 ? ((size_t)(by / g->vs) * g->mcux + bx / g->hs) * g->bpm + (by % g->vs) * g->hs + bx % g->hs
+                           : ((size_t)by * g->mcux + bx) * g->bpm + nl + c - 1;
+      pe_block(e, sc, c, coef + slot * 64, last_dc);
+    }
+  }
+  pe_eobrun(e);
+  if (e->w) bw_flush(e->w);
+}
+
+MJO_API int mjo_encode_progressive_coefficients(const int16_t *coef, int W, int H, int quality, int css,
+                                                int restart_interval, uint8_t **out, size_t *out_len) {
+  geom_t g;
+  if (make_geom(&g, W, H, css)) return -1;
+  if (restart_interval < 0 || restart_interval > 65535) return -1;
+  bw_t w; memset(&w, 0, sizeof w);
+  uint16_t qt[2][64];
+  mjo_quant_table(quality, 0, qt[0]); mjo_quant_table(quality, 1, qt[1]);
+  bw_u16(&w, 0xFFD8);
+  bw_u16(&w, 0xFFE0); bw_u16(&w, 16);
+  bw_byte(&w, 'J'); bw_byte(&w, 'F'); bw_byte(&w, 'I'); bw_byte(&w, 'F'); bw_byte(&w, 0);
+  bw_byte(&w, 1); bw_byte(&w, 1); bw_byte(&w, 0); bw_u16(&w, 1); bw_u16(&w, 1); bw_byte(&w, 0); bw_byte(&w, 0);
+  for (int t = 0; t < 2; t++) {
+    bw_u16(&w, 0xFFDB); bw_u16(&w, 67); bw_byte(&w, t);
+    for (int k = 0; k < 64; k++) bw_byte(&w, qt[t][k_zigzag[k]]);
+  }
+  bw_u16(&w, 0xFFC2); bw_u16(&w, 17); bw_byte(&w, 8); bw_u16(&w, H); bw_u16(&w, W); bw_byte(&w, 3);
+  bw_byte(&w, 1); bw_byte(&w, (g.hs << 4) | g.vs); bw_byte(&w, 0);
+  bw_byte(&w, 2); bw_byte(&w, 0x11); bw_byte(&w, 1);
+  bw_byte(&w, 3); bw_byte(&w, 0x11); bw_byte(&w, 1);
+  uint32_t *cnt = (uint32_t *)malloc(2 * 257 * sizeof(uint32_t));
+  if (!cnt) { free(w.p); return -2; }
+  int dri_sent = 0;
+  for (int s = 0; s < 10; s++) {
+    const pscan_t *sc = &k_simple_progression[s];
+    penc_t e; memset(&e, 0, sizeof e);
+    htab_t tab[2];
+    const int need_tab = !(sc->Ss == 0 && sc->Ah != 0);      /* a DC refinement scan has no Huffman-coded symbols */
+    if (need_tab) {
+      memset(cnt, 0, 2 * 257 * sizeof(uint32_t));
+      e.w = NULL; e.count[0] = cnt; e.count[1] = cnt + 257;
+      pe_scan(&e, sc, &g, W, H, coef, restart_interval);
+      for (int t = 0; t < 2; t++) {
+        int used = sc->ncomp > 1 ? 1 : ((sc->comp[0] ? 1 : 0) == t);
+        if (!used) continue;
+        memset(&tab[t], 0, sizeof tab[t]);
+        if (mjo_gen_optimal_table(cnt + t * 257, tab[t].bits, tab[t].vals) < 0) { free(cnt); free(w.p); return -3; }
+        derive_codes(&tab[t]);
+        write_dht(&w, &tab[t], (sc->Ss == 0 ? 0x00 : 0x10) | t);
+      }
+    }
+    if (restart_interval && !dri_sent) { bw_u16(&w, 0xFFDD); bw_u16(&w, 4); bw_u16(&w, restart_interval); dri_sent = 1; }
+    bw_u16(&w, 0xFFDA); bw_u16(&w, 6 + 2 * sc->ncomp); bw_byte(&w, sc->ncomp);
+    for (int i = 0; i < sc->ncomp; i++) {
+      const int c = sc->comp[i], t = c ? 1 : 0;
+      bw_byte(&w, c + 1);
+      /* jcmarker.c emit_sos: a progressive scan names only the table kind it uses (DC xor AC); the other nibble is 0,
+       * and a DC refinement scan names none */
+      bw_byte(&w, sc->Ss == 0 ? (sc->Ah == 0 ? (t << 4) : 0) : t);
+    }
+    bw_byte(&w, sc->Ss); bw_byte(&w, sc->Se); bw_byte(&w, (sc->Ah << 4) | sc->Al);
+    e.w = &w; e.tab[0] = &tab[0]; e.tab[1] = &tab[1];
+    pe_scan(&e, sc, &g, W, H, coef, restart_interval);
+  }
+  free(cnt);
+  bw_u16(&w, 0xFFD9);
+  *out = w.p; *out_len = w.n;
+  return 0;
+}
+
+MJO_API int mjo_encode_progressive(const uint8_t *src, int W, int H, size_t stride, int pixfmt, int quality, int css,
+                                   int restart_interval, uint8_t **out, size_t *out_len) {
+  geom_t g;
+  if (make_geom(&g, W, H, css)) return -1;
+  size_t n = (size_t)g.mcux * g.mcuy * g.bpm * 64;
+  int16_t *coef = (int16_t *)malloc(n * sizeof(int16_t));
+  if (!coef) return -2;
+  int rc = mjo_coefficients(src, W, H, stride, pixfmt, quality, css, coef);
+  if (!rc) rc = mjo_encode_progressive_coefficients(coef, W, H, quality, css, restart_interval, out, out_len);
+  free(coef);
+  return rc;
+}

@@ -196,6 +196,19 @@ def encode(img, quality=95, css=0, optimize=True, restart_interval=0, pixfmt="rg
     return _take(pp, ln)
 
 
+def encode_progressive(img, quality=95, css=0, restart_interval=0, pixfmt="rgb"):
+    """Progressive (SOF2) file with libjpeg's default scan script and one optimal table per scan."""
+    img, W, H, stride, fmt = _img_args(img, pixfmt)
+    pp, ln = C.c_void_p(), C.c_size_t()
+    L = lib()
+    L.mjo_encode_progressive.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    rc = L.mjo_encode_progressive(img.ctypes.data, W, H, stride, fmt, quality, css, restart_interval, C.byref(pp), C.byref(ln))
+    if rc:
+        raise RuntimeError("mjo_encode_progressive rc=%d" % rc)
+    return _take(pp, ln)
+
+
 def decode_info(jpg):
     info = np.zeros(8, np.int32)
     buf = np.frombuffer(jpg, np.uint8)

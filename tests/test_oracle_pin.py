@@ -138,3 +138,32 @@ def test_stage_apis_are_consistent(oracle):
     assert a == oracle.encode(img[..., ::-1], 95, 1, True, 0, "bgr")
     assert a == oracle.encode(img.transpose(2, 0, 1), 95, 1, True, 0, "rgb_planar")
     assert a == oracle.encode(img[..., ::-1].transpose(2, 0, 1), 95, 1, True, 0, "bgr_planar")
+
+
+# ---- progressive mode (reference ImageCompressorImpl.cu:28): oracle restatement of libjpeg's scan script + jcphuff procedures
+def _pil_progressive(img, q, ss, **kw):
+    from PIL import ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 26)     # libjpeg cannot suspend while writing progressive output
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", quality=q, subsampling=ss, progressive=True, **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("size", [(64, 64), (17, 33), (200, 136), (1, 1), (333, 77)])
+@pytest.mark.parametrize("ss", [0, 1, 2])
+def test_progressive_bytes_equal_libjpeg_turbo(oracle, size, ss):
+    """Byte-identical files: scan script, EOB runs, correction-bit buffering and flush rules, one optimal table per scan."""
+    W, H = size
+    rng = np.random.default_rng(W + ss)
+    flat = np.full((H, W, 3), 200, np.uint8)
+    flat[H // 3:, W // 2:] = (10, 90, 250)
+    for img in (oracle.synth_rgb(W, H), rng.integers(0, 256, (H, W, 3), dtype=np.uint8), flat):
+        for q in (95, 35, 100):
+            assert oracle.encode_progressive(img, q, ss) == _pil_progressive(img, q, ss), (q,)
+
+
+@pytest.mark.parametrize("ri", [1, 7, 40])
+def test_progressive_with_restart_interval(oracle, ri):
+    img = oracle.synth_rgb(176, 120)
+    for ss in (0, 1, 2):
+        assert oracle.encode_progressive(img, 85, ss, ri) == _pil_progressive(img, 85, ss, restart_marker_blocks=ri)

@@ -63,6 +63,12 @@ typedef struct mij_encoder_params {
    * full image; strip_mcu_rows == 0 means the whole image. The strip's first MCU must fall on a restart-interval
    * boundary (guaranteed when restart_interval divides the MCUs per row, which AUTO always picks). */
   int strip_mcu_row0, strip_mcu_rows;
+  /* nvjpegEncoderParamsSetEncoding (ImageCompressorImpl.cu:28): 0 = baseline sequential (SOF0, one scan), the default
+   * and the fast path; 1 = progressive (SOF2): the same coefficients coded as the ten scans of libjpeg's default script
+   * with an optimal Huffman table per scan -- byte-identical to libjpeg-turbo's progressive output, a few per cent
+   * smaller than baseline, many times slower to produce (ten gather + emit passes). Whole images only (no strips);
+   * optimized_huffman is implied. */
+  int progressive;
 } mij_encoder_params;
 
 /* Geometry derived from the parameters (useful to callers that shard). */

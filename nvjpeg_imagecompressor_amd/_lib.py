@@ -30,7 +30,7 @@ EXPORTS = (
 class EncoderParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("optimized_huffman", C.c_int),
                 ("css", C.c_int), ("restart_interval", C.c_int), ("device", C.c_int),
-                ("strip_mcu_row0", C.c_int), ("strip_mcu_rows", C.c_int)]
+                ("strip_mcu_row0", C.c_int), ("strip_mcu_rows", C.c_int), ("progressive", C.c_int)]
 
 
 class Geometry(C.Structure):

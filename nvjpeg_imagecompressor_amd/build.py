@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmijpeg.so")
 SOURCES = ["mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip"]
-HEADERS = ["mij_internal.h", "k_common.inc", "k_transform.inc", "k_batch.inc", "k_stats.inc", "k_tables.inc", "k_encode.inc", "k_finish.inc", "k_synth.inc", "k_decode.inc", "k_decode_scans.inc", "k_decode_par.inc", "k_launch.inc", os.path.join("..", "..", "include", "mi_jpeg.h")]
+HEADERS = ["mij_internal.h", "k_common.inc", "k_transform.inc", "k_batch.inc", "k_stats.inc", "k_tables.inc", "k_encode.inc", "k_encode_prog.inc", "k_finish.inc", "k_synth.inc", "k_decode.inc", "k_decode_scans.inc", "k_decode_par.inc", "k_launch.inc", os.path.join("..", "..", "include", "mi_jpeg.h")]
 ARCH = "gfx950"
 
 

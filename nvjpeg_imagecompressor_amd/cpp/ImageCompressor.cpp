@@ -126,6 +126,7 @@ void NvjpegCompressRunner::setSamplingFactors(int css) { compressor->p.css = css
 void NvjpegCompressRunner::setQuality(int q) { compressor->p.quality = q; }
 void NvjpegCompressRunner::setOptimizedHuffman(bool o) { compressor->p.optimized_huffman = o ? 1 : 0; }
 void NvjpegCompressRunner::setRestartInterval(int m) { compressor->p.restart_interval = m; }
+void NvjpegCompressRunner::setProgressive(bool on) { compressor->p.progressive = on ? 1 : 0; }
 void NvjpegCompressRunner::setDevice(int d) { compressor->p.device = d; }
 void NvjpegCompressRunner::setVerbose(bool v) { compressor->verbose = v; }
 const char *NvjpegCompressRunner::lastError() const { return compressor->err.c_str(); }

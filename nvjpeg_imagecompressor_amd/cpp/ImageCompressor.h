@@ -50,6 +50,7 @@ class NVJPEG_COMPRESS_RUNNER_API NvjpegCompressRunner {
   void setQuality(int quality);
   void setOptimizedHuffman(bool optimize);
   void setRestartInterval(int mcus);       // -1 = automatic
+  void setProgressive(bool progressive);   // the reference's encoding (ImageCompressorImpl.cu:28); default false = baseline, the fast path
   void setDevice(int device);
   void setVerbose(bool verbose);
   const char *lastError() const;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace mij;
 
@@ -24,6 +25,7 @@ struct mij_encoder {
   size_t coef_count = 0;
   uint8_t *d_scratch = nullptr;
   size_t slot_bytes = 0;
+  size_t slot_bytes_1 = 0;   // progressive: slot of an interval of a single-component scan
   long long nseg = 0;
   uint32_t *d_seg_bytes = nullptr, *d_seg_ff = nullptr;
   unsigned long long *d_seg_off = nullptr, *d_chunk_total = nullptr, *d_chunk_base = nullptr;
@@ -179,6 +181,7 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   g.last_strip = (row0 + rows == g.mcuy);
   if (!g.last_strip && (g.mcu_count % ri)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not end on a restart-interval boundary"); }
   g.y_origin = row0 * 8 * vs;
+  if (p->progressive && (row0 != 0 || rows != g.mcuy)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "progressive output is for whole images (no strips)"); }
   e->nseg = (g.mcu_count + ri - 1) / ri;
   e->coef_count = (size_t)g.mcu_count * g.bpm * 64;
   e->slot_bytes = (((size_t)ri * g.bpm * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
@@ -194,11 +197,21 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   e->d_hist = e->d_hist_own;
   CRCHK(hipMalloc(&e->d_coef, e->coef_count * sizeof(int16_t)));
   CRCHK(hipMalloc(&e->d_dc, (e->coef_count / 64) * sizeof(int16_t)));
-  CRCHK(hipMalloc(&e->d_scratch, e->slot_bytes * (size_t)e->nseg));
-  CRCHK(hipMalloc(&e->d_seg_bytes, (size_t)e->nseg * sizeof(uint32_t)));
-  CRCHK(hipMalloc(&e->d_seg_ff, (size_t)e->nseg * sizeof(uint32_t)));
-  CRCHK(hipMalloc(&e->d_seg_off, (size_t)e->nseg * sizeof(unsigned long long)));
-  { const size_t nch = (size_t)((e->nseg + 1023) / 1024);
+  // Progressive: a single-component scan has one block per "MCU", hence up to nl times as many restart intervals
+  // (each with a smaller slot); size the per-interval arrays and the scratch for the largest scan.
+  size_t seg_alloc = (size_t)e->nseg, scratch_alloc = e->slot_bytes * (size_t)e->nseg;
+  if (p->progressive) {
+    const long long luma_blocks = (long long)g.wib0 * g.hib0;
+    const size_t nseg_y = (size_t)((luma_blocks + ri - 1) / ri);
+    seg_alloc = std::max(seg_alloc, nseg_y);
+    e->slot_bytes_1 = (((size_t)ri * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
+    scratch_alloc = std::max(scratch_alloc, e->slot_bytes_1 * nseg_y);
+  }
+  CRCHK(hipMalloc(&e->d_scratch, scratch_alloc));
+  CRCHK(hipMalloc(&e->d_seg_bytes, seg_alloc * sizeof(uint32_t)));
+  CRCHK(hipMalloc(&e->d_seg_ff, seg_alloc * sizeof(uint32_t)));
+  CRCHK(hipMalloc(&e->d_seg_off, seg_alloc * sizeof(unsigned long long)));
+  { const size_t nch = (seg_alloc + 1023) / 1024;
     CRCHK(hipMalloc(&e->d_chunk_total, nch * sizeof(unsigned long long)));
     CRCHK(hipMalloc(&e->d_chunk_base, nch * sizeof(unsigned long long))); }
   CRCHK(hipMalloc(&e->d_ovf, sizeof(uint32_t)));
@@ -256,7 +269,7 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
     e->timed_run = e->timing;
     e->transformed = false;
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[0], s));
-    if (e->p.optimized_huffman) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
+    if (e->p.optimized_huffman && !e->p.progressive) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
   }
   TransformArgs a{};
   a.src = (const uint8_t *)d_src; a.pitch = pitch; a.plane_stride = plane_stride;
@@ -270,11 +283,11 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   a.coef = e->d_coef + (size_t)skip * g.bpm * 64;
   a.dc = e->d_dc + (size_t)skip * g.bpm;
   memcpy(a.recip, e->hq.recip, sizeof(a.recip));
-  a.hist = e->p.optimized_huffman ? e->d_hist : nullptr;
+  a.hist = (e->p.optimized_huffman && !e->p.progressive) ? e->d_hist : nullptr;   // progressive gathers per scan instead
   if (sub.mcu_count > 0) HIPCHK(e, launch_transform(sub, a, interleaved ? 1 : 0, s));
   if (last) {
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
-    if (e->p.optimized_huffman) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
+    if (e->p.optimized_huffman && !e->p.progressive) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
     e->transformed = true;
   }
@@ -304,6 +317,100 @@ static int run_tail(mij_encoder *e, hipStream_t s, bool tables) {
   return MIJ_OK;
 }
 
+// Progressive output (k_encode_prog.inc): the ten scans of libjpeg's jpeg_simple_progression, each = gather statistics ->
+// K3 builds the table(s) -> the host writes DHT + SOS behind the previous scan -> emit -> K5/K6. The size of a scan is
+// needed to place the next one, so this route synchronises once per scan and returns with the file complete.
+static int encode_progressive(mij_encoder *e, hipStream_t s) {
+  const Geom &g = e->g;
+  struct PS { int ncomp, comp[3], Ss, Se, Ah, Al; };
+  static const PS script[10] = {{3, {0, 1, 2}, 0, 0, 0, 1}, {1, {0, 0, 0}, 1, 5, 0, 2}, {1, {2, 0, 0}, 1, 63, 0, 1}, {1, {1, 0, 0}, 1, 63, 0, 1},
+                                {1, {0, 0, 0}, 6, 63, 0, 2}, {1, {0, 0, 0}, 1, 63, 2, 1}, {3, {0, 1, 2}, 0, 0, 1, 0}, {1, {2, 0, 0}, 1, 63, 1, 0},
+                                {1, {1, 0, 0}, 1, 63, 1, 0}, {1, {0, 0, 0}, 1, 63, 1, 0}};
+  static const uint32_t one = 1;
+  std::vector<uint8_t> fh;   // frame header: SOI APP0 DQT DQT SOF2 (same order as the baseline header K3 writes)
+  auto put = [&](int b) { fh.push_back((uint8_t)b); };
+  auto put16 = [&](int v) { put(v >> 8); put(v & 255); };
+  put16(0xFFD8);
+  put16(0xFFE0); put16(16); put('J'); put('F'); put('I'); put('F'); put(0); put(1); put(1); put(0); put16(1); put16(1); put(0); put(0);
+  static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+                                 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61,
+                                 54, 47, 55, 62, 63};
+  for (int t = 0; t < 2; t++) { put16(0xFFDB); put16(67); put(t); for (int k = 0; k < 64; k++) put(e->hq.q[t][zz[k]]); }
+  put16(0xFFC2); put16(17); put(8); put16(g.H); put16(g.W); put(3);
+  put(1); put((g.hs << 4) | g.vs); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
+  uint8_t *const file = e->d_out + HDR_AREA;
+  size_t off = 0;
+  bool dri_sent = false;
+  Geom g2 = g; g2.last_strip = 0; g2.mcu_first = 0;     // K6: RSTn numbering restarts in every scan, never an EOI
+  DeviceTables ht;
+  DeviceResult hr;
+  for (int si = 0; si < 10; si++) {
+    const PS &ps = script[si];
+    ScanDesc sd{};
+    sd.kind = ps.Ss == 0 ? (ps.Ah == 0 ? 1 : 2) : (ps.Ah == 0 ? 3 : 4);
+    sd.ncomp = ps.ncomp;
+    for (int i = 0; i < 3; i++) sd.comp[i] = ps.comp[i];
+    sd.Ss = ps.Ss; sd.Se = ps.Se; sd.Al = ps.Al; sd.ri = g.ri;
+    size_t slot;
+    if (ps.ncomp > 1) { sd.bw = g.mcux; sd.bh = g.mcuy; sd.nmcu = (long long)g.mcux * g.mcuy; slot = e->slot_bytes; }
+    else {
+      const int c = ps.comp[0];
+      const int cw = c == 0 ? g.W : (g.W + g.hs - 1) / g.hs, ch = c == 0 ? g.H : (g.H + g.vs - 1) / g.vs;
+      sd.bw = (cw + 7) / 8; sd.bh = (ch + 7) / 8; sd.nmcu = (long long)sd.bw * sd.bh; slot = e->slot_bytes_1;
+    }
+    const long long nseg = (sd.nmcu + g.ri - 1) / g.ri;
+    if (sd.kind != 2) {
+      HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
+      HIPCHK(e, launch_prog_encode(g, sd, 1, e->d_coef, e->d_tab, e->d_scratch, slot, e->d_seg_bytes, e->d_seg_ff, e->d_hist, nseg, s));
+      // K3 builds all four tables: give the ones this scan does not use a single count so that they are well formed
+      for (int w = 0; w < 4; w++) {
+        const bool used = sd.kind == 1 ? (w == 0 || w == 2) : (w == (ps.comp[0] ? 3 : 1));
+        if (!used) HIPCHK(e, hipMemcpyAsync(e->d_hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, s));
+      }
+      HIPCHK(e, launch_build_tables(g, e->d_hist, 1, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
+      HIPCHK(e, hipMemcpyAsync(&ht, e->d_tab, sizeof ht, hipMemcpyDeviceToHost, s));
+      HIPCHK(e, hipStreamSynchronize(s));
+    }
+    std::vector<uint8_t> sh;   // DHT(s) of the tables this scan uses, DRI before the first SOS, SOS (jcmarker.c write_scan_header)
+    auto sput = [&](int b) { sh.push_back((uint8_t)b); };
+    auto sput16 = [&](int v) { sput(v >> 8); sput(v & 255); };
+    auto dht = [&](int w, int tcth) {
+      const int nv = (int)ht.nvals[w];
+      sput16(0xFFC4); sput16(19 + nv); sput(tcth);
+      for (int i = 1; i <= 16; i++) sput(ht.bits[w][i]);
+      for (int i = 0; i < nv; i++) sput(ht.vals[w][i]);
+    };
+    if (sd.kind == 1) { dht(0, 0x00); dht(2, 0x01); }
+    else if (sd.kind >= 3) dht(ps.comp[0] ? 3 : 1, 0x10 | (ps.comp[0] ? 1 : 0));
+    if (!dri_sent) { sput16(0xFFDD); sput16(4); sput16(g.ri); dri_sent = true; }
+    sput16(0xFFDA); sput16(6 + 2 * ps.ncomp); sput(ps.ncomp);
+    for (int i = 0; i < ps.ncomp; i++) {
+      const int c = ps.comp[i], t = c ? 1 : 0;
+      sput(c + 1);
+      sput(ps.Ss == 0 ? (ps.Ah == 0 ? (t << 4) : 0) : t);   // jcmarker.c emit_sos: only the table kind the scan uses
+    }
+    sput(ps.Ss); sput(ps.Se); sput((ps.Ah << 4) | ps.Al);
+    if (si == 0) sh.insert(sh.begin(), fh.begin(), fh.end());
+    if (off + sh.size() + 2 > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "output buffer too small for the progressive file");
+    HIPCHK(e, hipMemcpyAsync(file + off, sh.data(), sh.size(), hipMemcpyHostToDevice, s));
+    off += sh.size();
+    HIPCHK(e, launch_prog_encode(g, sd, 0, e->d_coef, e->d_tab, e->d_scratch, slot, e->d_seg_bytes, e->d_seg_ff, e->d_hist, nseg, s));
+    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
+    HIPCHK(e, launch_compact(g2, e->d_scratch, slot, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, nseg, file + off, e->capacity - off, e->d_res, s));
+    HIPCHK(e, hipMemcpyAsync(&hr, e->d_res, sizeof hr, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));   // also keeps `sh` alive until its upload is done
+    if (hr.scan_bytes > e->capacity - off) return fail(e, MIJ_ERR_OVERFLOW, "output buffer too small for the progressive file");
+    off += (size_t)hr.scan_bytes - 2;     // K6 ends every interval with RSTn; the last one of a scan has none: overwritten next
+  }
+  static const uint8_t eoi[2] = {0xFF, 0xD9};
+  HIPCHK(e, hipMemcpyAsync(file + off, eoi, 2, hipMemcpyHostToDevice, s));
+  off += 2;
+  HIPCHK(e, hipStreamSynchronize(s));
+  e->h_res->scan_bytes = off; e->h_res->header_bytes = 0; e->h_res->flags = 0;
+  e->issued = true;
+  return MIJ_OK;
+}
+
 int mij_encode_entropy(mij_encoder *e, void *stream) {
   if (!e) return MIJ_ERR_INVALID_ARG;
   if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_entropy called before mij_encode_transform");
@@ -311,6 +418,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   e->last_stream = s;
   const Geom &g = e->g;
+  if (e->p.progressive) { e->timed_run = false; return encode_progressive(e, s); }
   // Fixed (Annex K) tables and the header do not depend on the image: built once per handle.
   if (e->p.optimized_huffman || !e->static_tables_ready) {
     int rc = run_tail(e, s, true);

@@ -107,6 +107,9 @@ struct ScanDesc {
 
 hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, const unsigned long long *seg_pos,
                               long long nseg, const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
+// Progressive scans (k_encode_prog.inc): gather != 0 counts symbols into hist (4 x 257), otherwise writes the interval slots.
+hipError_t launch_prog_encode(const Geom &g, const ScanDesc &sd, int gather, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
+                              size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, long long nseg, hipStream_t s);
 // Parallel (self-synchronising) decode of a baseline interleaved scan. `ws` is a workspace of par_workspace_bytes().
 size_t par_workspace_bytes(size_t scan_len, long long nseg);
 hipError_t launch_par_decode(const Geom &g, const uint8_t *scan, size_t n, const unsigned long long *seg_pos, long long nseg,

@@ -20,6 +20,7 @@ namespace mij {
 #include "k_tables.inc"
 #include "k_encode.inc"
 #include "k_finish.inc"
+#include "k_encode_prog.inc"
 #include "k_synth.inc"
 #include "k_decode.inc"
 #include "k_decode_scans.inc"

@@ -25,11 +25,11 @@ class Encoder:
     """One encoder state + device workspace (initCompressEnv / destoryCompressEnv, reference ImageCompressorImpl.cu:19-65)."""
 
     def __init__(self, width, height, quality=95, optimized_huffman=True, css=0, restart_interval=MIJ_RESTART_AUTO,
-                 device=0, strip_mcu_row0=0, strip_mcu_rows=0):
+                 device=0, strip_mcu_row0=0, strip_mcu_rows=0, progressive=False):
         self._L = _lib.load()
         self._h = C.c_void_p()
         p = _lib.EncoderParams(width, height, quality, int(bool(optimized_huffman)), _css_value(css),
-                               restart_interval, device, strip_mcu_row0, strip_mcu_rows)
+                               restart_interval, device, strip_mcu_row0, strip_mcu_rows, int(bool(progressive)))
         rc = self._L.mij_encoder_create(C.byref(p), C.byref(self._h))
         if rc:
             msg = self._L.mij_last_error(None)

@@ -1,0 +1,68 @@
+"""Progressive (SOF2) output -- the encoding the reference configures (ImageCompressorImpl.cu:28) -- through the C ABI,
+byte-for-byte against the oracle's restatement of libjpeg's progressive encoder (itself byte-identical to libjpeg-turbo,
+tests/test_oracle_pin.py), plus directly against Pillow where Pillow can be given the same restart interval."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image, ImageFile
+
+ImageFile.MAXBLOCK = 1 << 26
+pytestmark = pytest.mark.gpu
+
+
+def _images(oracle, W, H, seed):
+    rng = np.random.default_rng(seed)
+    yield oracle.synth_rgb(W, H)
+    yield rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    flat = np.full((H, W, 3), 200, np.uint8)
+    flat[H // 3:, W // 2:] = (10, 90, 250)
+    yield flat
+
+
+@pytest.mark.parametrize("css", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("size", [(64, 64), (17, 33), (200, 136), (1, 1), (333, 77), (1040, 136)])
+def test_progressive_matches_oracle(mij, oracle, css, size):
+    W, H = size
+    for n, img in enumerate(_images(oracle, W, H, css)):
+        for q in (95, 35, 100):
+            with mij.Encoder(W, H, q, True, css, progressive=True) as enc:
+                ri = enc.geometry["restart_interval"]
+                got = enc.encode_host(img, "rgb")
+            want = oracle.encode_progressive(img, q, css, ri)
+            assert len(got) == len(want), (n, q, len(got), len(want))
+            assert got == want, (n, q, next(i for i in range(len(want)) if got[i] != want[i]))
+
+
+@pytest.mark.parametrize("ri", [1, 7, 40])
+def test_progressive_matches_libjpeg_turbo_directly(mij, oracle, ri):
+    img = oracle.synth_rgb(176, 120)
+    for css in (0, 1, 2):
+        with mij.Encoder(176, 120, 85, True, css, restart_interval=ri, progressive=True) as enc:
+            got = enc.encode_host(img, "rgb")
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=85, subsampling=css, progressive=True, restart_marker_blocks=ri)
+        assert got == b.getvalue()
+        dec = np.asarray(Image.open(io.BytesIO(got)).convert("RGB"))
+        assert dec.shape == img.shape
+
+
+def test_progressive_smaller_than_baseline_and_same_pixels(mij, oracle):
+    W, H = 2080, 1000
+    img = oracle.synth_rgb(W, H)
+    with mij.Encoder(W, H, 95, True, 1) as enc:
+        base = enc.encode_host(img, "rgb")
+    with mij.Encoder(W, H, 95, True, 1, progressive=True) as enc:
+        prog = enc.encode_host(img, "rgb")
+        assert prog == oracle.encode_progressive(img, 95, 1, enc.geometry["restart_interval"])
+    assert len(prog) < len(base)
+    a = np.asarray(Image.open(io.BytesIO(base)).convert("RGB"))
+    b = np.asarray(Image.open(io.BytesIO(prog)).convert("RGB"))
+    assert np.array_equal(a, b)          # same quantised coefficients
+    with mij.Decoder() as dec:           # and our own decoder reads it back
+        assert np.array_equal(dec.decode_host(prog, "rgb"), b)
+
+
+def test_progressive_rejects_strips(mij):
+    with pytest.raises(mij.MiJpegError, match="whole images"):
+        mij.Encoder(512, 512, 90, True, 0, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)

@@ -36,6 +36,16 @@ def test_fullsize_bit_exact(mij, big_image, css, optimize):
     assert "%08x" % zlib.crc32(jpg) == GOLD["cases"][key]["crc32"]
 
 
+def test_fullsize_progressive_bit_exact(mij, big_image):
+    """Progressive output at the BASELINE size: the oracle's (= libjpeg's) file, by length and CRC."""
+    with mij.Encoder(W, H, 95, True, 1, progressive=True) as enc:
+        assert enc.geometry["restart_interval"] == 104
+        enc.encode_device(big_image.data_ptr(), W * 3, "rgb")
+        jpg = enc.retrieve()
+    gold = GOLD["cases"]["css1_ri104_progressive"]
+    assert len(jpg) == gold["len"] and "%08x" % zlib.crc32(jpg) == gold["crc32"]
+
+
 def test_fullsize_stock_decoder_psnr(mij, oracle, big_image):
     """Headline config (8320x40000 q95 4:2:2 optimised): decodes in libjpeg-turbo; PSNR equals libjpeg-turbo's own
     encode of the same input (31.162 dB) within the north-star's 0.05 dB."""

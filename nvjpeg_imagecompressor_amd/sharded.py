@@ -127,7 +127,7 @@ def _buffer(torch, cache, n, device):
 
 
 def make_hip_strip_encoder(torch, width, height, quality, optimize, css, rank, world, device_index, fmt="bgr",
-                           restart_interval=-1):
+                           restart_interval=-1, progressive=False):
     """Creates this rank's Encoder for its strip plus the geometry needed to fill the strip with pixels."""
     probe = Encoder(width, height, quality, optimize, css, restart_interval, device_index, 0, 1)
     g0 = probe.geometry
@@ -136,5 +136,9 @@ def make_hip_strip_encoder(torch, width, height, quality, optimize, css, rank, w
     r0, r1 = partition_mcu_rows(g0["mcu_rows"], world, rank, unit)
     if r1 <= r0:
         raise ValueError("more ranks than restart-aligned strips: rank %d would be empty" % rank)
+    if progressive:
+        if world != 1:
+            raise ValueError("progressive output is not sharded: every scan spans the whole image")
+        return Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, progressive=True)
     enc = Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, r0, r1 - r0)
     return enc

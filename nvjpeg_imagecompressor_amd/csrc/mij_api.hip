@@ -25,7 +25,24 @@ struct mij_encoder {
   size_t coef_count = 0;
   uint8_t *d_scratch = nullptr;
   size_t slot_bytes = 0;
-  size_t slot_bytes_1 = 0;   // progressive: slot of an interval of a single-component scan
+  // progressive output: the ten scans run concurrently, each with its own workspace (allocated only when asked for)
+  struct ProgScan {
+    ScanDesc sd{};
+    int Ah = 0;
+    long long nseg = 0;
+    size_t slot = 0;
+    uint8_t *scratch = nullptr;
+    uint32_t *seg_bytes = nullptr, *seg_ff = nullptr, *hist = nullptr, *ovf = nullptr;
+    unsigned long long *seg_off = nullptr, *chunk_total = nullptr, *chunk_base = nullptr;
+    DeviceTables *tab = nullptr;
+    DeviceResult *res = nullptr;
+  } ps[10];
+  uint8_t *d_prog = nullptr;          // one allocation behind all of the above
+  hipStream_t prog_stream[4]{};
+  hipEvent_t prog_ev[5]{};
+  bool prog_streams = false;
+  DeviceTables *h_prog_tab = nullptr; // pinned: the ten tables + results come back in one go
+  DeviceResult *h_prog_res = nullptr;
   long long nseg = 0;
   uint32_t *d_seg_bytes = nullptr, *d_seg_ff = nullptr;
   unsigned long long *d_seg_off = nullptr, *d_chunk_total = nullptr, *d_chunk_base = nullptr;
@@ -137,6 +154,13 @@ void mij_encoder_destroy(mij_encoder *e) {
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->ev_ok) for (auto &v : e->ev) (void)hipEventDestroy(v);
+  (void)hipFree(e->d_prog);
+  if (e->h_prog_tab) (void)hipHostFree(e->h_prog_tab);
+  if (e->h_prog_res) (void)hipHostFree(e->h_prog_res);
+  if (e->prog_streams) {
+    for (auto &q : e->prog_stream) (void)hipStreamDestroy(q);
+    for (auto &v : e->prog_ev) (void)hipEventDestroy(v);
+  }
   if (e->host_streams) {
     (void)hipStreamDestroy(e->s_copy); (void)hipStreamDestroy(e->s_work);
     for (auto &v : e->ev_chunk) (void)hipEventDestroy(v);
@@ -197,16 +221,7 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   e->d_hist = e->d_hist_own;
   CRCHK(hipMalloc(&e->d_coef, e->coef_count * sizeof(int16_t)));
   CRCHK(hipMalloc(&e->d_dc, (e->coef_count / 64) * sizeof(int16_t)));
-  // Progressive: a single-component scan has one block per "MCU", hence up to nl times as many restart intervals
-  // (each with a smaller slot); size the per-interval arrays and the scratch for the largest scan.
-  size_t seg_alloc = (size_t)e->nseg, scratch_alloc = e->slot_bytes * (size_t)e->nseg;
-  if (p->progressive) {
-    const long long luma_blocks = (long long)g.wib0 * g.hib0;
-    const size_t nseg_y = (size_t)((luma_blocks + ri - 1) / ri);
-    seg_alloc = std::max(seg_alloc, nseg_y);
-    e->slot_bytes_1 = (((size_t)ri * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
-    scratch_alloc = std::max(scratch_alloc, e->slot_bytes_1 * nseg_y);
-  }
+  const size_t seg_alloc = (size_t)e->nseg, scratch_alloc = e->slot_bytes * (size_t)e->nseg;
   CRCHK(hipMalloc(&e->d_scratch, scratch_alloc));
   CRCHK(hipMalloc(&e->d_seg_bytes, seg_alloc * sizeof(uint32_t)));
   CRCHK(hipMalloc(&e->d_seg_ff, seg_alloc * sizeof(uint32_t)));
@@ -219,6 +234,51 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity));
   CRCHK(hipMalloc(&e->d_res, sizeof(DeviceResult)));
   CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
+  if (p->progressive) {
+    // libjpeg's jpeg_simple_progression for YCbCr (jcparam.c); a single-component scan has one block per "MCU"
+    static const int script[10][6] = {{3, 0, 0, 0, 0, 1}, {1, 0, 1, 5, 0, 2}, {1, 2, 1, 63, 0, 1}, {1, 1, 1, 63, 0, 1}, {1, 0, 6, 63, 0, 2},
+                                      {1, 0, 1, 63, 2, 1}, {3, 0, 0, 0, 1, 0}, {1, 2, 1, 63, 1, 0}, {1, 1, 1, 63, 1, 0}, {1, 0, 1, 63, 1, 0}};
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_scr[10], o_sb[10], o_sf[10], o_so[10], o_ct[10], o_cb[10], o_h[10], o_t[10], o_r[10], o_v[10];
+    for (int i = 0; i < 10; i++) {
+      mij_encoder::ProgScan &q = e->ps[i];
+      ScanDesc &sd = q.sd;
+      sd.ncomp = script[i][0];
+      sd.comp[0] = script[i][1]; sd.comp[1] = 1; sd.comp[2] = 2;
+      if (sd.ncomp == 3) sd.comp[0] = 0;
+      sd.Ss = script[i][2]; sd.Se = script[i][3]; q.Ah = script[i][4]; sd.Al = script[i][5];
+      sd.kind = sd.Ss == 0 ? (q.Ah == 0 ? 1 : 2) : (q.Ah == 0 ? 3 : 4);
+      sd.ri = ri;
+      if (sd.ncomp > 1) { sd.bw = g.mcux; sd.bh = g.mcuy; q.slot = e->slot_bytes; }
+      else {
+        const int c = sd.comp[0];
+        const int cw = c == 0 ? g.W : (g.W + hs - 1) / hs, ch = c == 0 ? g.H : (g.H + vs - 1) / vs;
+        sd.bw = (cw + 7) / 8; sd.bh = (ch + 7) / 8;
+        q.slot = (((size_t)ri * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
+      }
+      sd.nmcu = (long long)sd.bw * sd.bh;
+      q.nseg = (sd.nmcu + ri - 1) / ri;
+      const size_t nch = (size_t)((q.nseg + 1023) / 1024);
+      o_scr[i] = take(q.slot * (size_t)q.nseg); o_sb[i] = take((size_t)q.nseg * 4); o_sf[i] = take((size_t)q.nseg * 4);
+      o_so[i] = take((size_t)q.nseg * 8); o_ct[i] = take(nch * 8); o_cb[i] = take(nch * 8); o_h[i] = take(4 * 257 * 4);
+      o_t[i] = take(sizeof(DeviceTables)); o_r[i] = take(sizeof(DeviceResult)); o_v[i] = take(4);
+    }
+    CRCHK(hipMalloc(&e->d_prog, total));
+    for (int i = 0; i < 10; i++) {
+      mij_encoder::ProgScan &q = e->ps[i];
+      q.scratch = e->d_prog + o_scr[i]; q.seg_bytes = (uint32_t *)(e->d_prog + o_sb[i]); q.seg_ff = (uint32_t *)(e->d_prog + o_sf[i]);
+      q.seg_off = (unsigned long long *)(e->d_prog + o_so[i]); q.chunk_total = (unsigned long long *)(e->d_prog + o_ct[i]);
+      q.chunk_base = (unsigned long long *)(e->d_prog + o_cb[i]); q.hist = (uint32_t *)(e->d_prog + o_h[i]);
+      q.tab = (DeviceTables *)(e->d_prog + o_t[i]); q.res = (DeviceResult *)(e->d_prog + o_r[i]); q.ovf = (uint32_t *)(e->d_prog + o_v[i]);
+      CRCHK(hipMemset(q.ovf, 0, 4));
+    }
+    CRCHK(hipHostMalloc(&e->h_prog_tab, 10 * sizeof(DeviceTables), hipHostMallocDefault));
+    CRCHK(hipHostMalloc(&e->h_prog_res, 10 * sizeof(DeviceResult), hipHostMallocDefault));
+    for (auto &st : e->prog_stream) CRCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &v : e->prog_ev) CRCHK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
+    e->prog_streams = true;
+  }
   for (auto &v : e->ev) CRCHK(hipEventCreate(&v));
   e->ev_ok = true;
 #undef CRCHK
@@ -317,95 +377,96 @@ static int run_tail(mij_encoder *e, hipStream_t s, bool tables) {
   return MIJ_OK;
 }
 
-// Progressive output (k_encode_prog.inc): the ten scans of libjpeg's jpeg_simple_progression, each = gather statistics ->
-// K3 builds the table(s) -> the host writes DHT + SOS behind the previous scan -> emit -> K5/K6. The size of a scan is
-// needed to place the next one, so this route synchronises once per scan and returns with the file complete.
+// Progressive output (k_encode_prog.inc): the ten scans of libjpeg's jpeg_simple_progression. Only the final placement
+// of a scan depends on the scans before it, so all ten are coded concurrently on four streams, each into its own
+// workspace: gather statistics -> K3 builds the table(s) -> emit -> K5 sizes; one synchronisation brings the tables and
+// sizes to the host, which writes DHT + SOS for every scan at its final offset and launches the ten compactions (K6)
+// concurrently. Returns with the file complete.
 static int encode_progressive(mij_encoder *e, hipStream_t s) {
   const Geom &g = e->g;
-  struct PS { int ncomp, comp[3], Ss, Se, Ah, Al; };
-  static const PS script[10] = {{3, {0, 1, 2}, 0, 0, 0, 1}, {1, {0, 0, 0}, 1, 5, 0, 2}, {1, {2, 0, 0}, 1, 63, 0, 1}, {1, {1, 0, 0}, 1, 63, 0, 1},
-                                {1, {0, 0, 0}, 6, 63, 0, 2}, {1, {0, 0, 0}, 1, 63, 2, 1}, {3, {0, 1, 2}, 0, 0, 1, 0}, {1, {2, 0, 0}, 1, 63, 1, 0},
-                                {1, {1, 0, 0}, 1, 63, 1, 0}, {1, {0, 0, 0}, 1, 63, 1, 0}};
   static const uint32_t one = 1;
-  std::vector<uint8_t> fh;   // frame header: SOI APP0 DQT DQT SOF2 (same order as the baseline header K3 writes)
-  auto put = [&](int b) { fh.push_back((uint8_t)b); };
-  auto put16 = [&](int v) { put(v >> 8); put(v & 255); };
-  put16(0xFFD8);
-  put16(0xFFE0); put16(16); put('J'); put('F'); put('I'); put('F'); put(0); put(1); put(1); put(0); put16(1); put16(1); put(0); put(0);
+  HIPCHK(e, hipEventRecord(e->prog_ev[4], s));            // the coefficients (K1 on `s`) are ready
+  for (int i = 0; i < 10; i++) {
+    mij_encoder::ProgScan &q = e->ps[i];
+    hipStream_t st = e->prog_stream[i & 3];
+    if (i < 4) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
+    if (q.sd.kind != 2) {
+      HIPCHK(e, hipMemsetAsync(q.hist, 0, 4 * 257 * sizeof(uint32_t), st));
+      HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+      // K3 builds all four tables: give the ones this scan does not use a single count so that they are well formed
+      for (int w = 0; w < 4; w++) {
+        const bool used = q.sd.kind == 1 ? (w == 0 || w == 2) : (w == (q.sd.comp[0] ? 3 : 1));
+        if (!used) HIPCHK(e, hipMemcpyAsync(q.hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, st));
+      }
+      // (K3 also writes a baseline header into the first HDR_AREA bytes of d_out; the progressive file starts after them)
+      HIPCHK(e, launch_build_tables(g, q.hist, 1, e->d_qt, q.tab, e->d_out, q.res, st));
+      HIPCHK(e, hipMemcpyAsync(&e->h_prog_tab[i], q.tab, sizeof(DeviceTables), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+    HIPCHK(e, launch_scan(q.seg_bytes, q.seg_ff, q.seg_off, q.nseg, q.chunk_total, q.chunk_base, q.ovf, q.res, st));
+    HIPCHK(e, hipMemcpyAsync(&e->h_prog_res[i], q.res, sizeof(DeviceResult), hipMemcpyDeviceToHost, st));
+  }
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamSynchronize(st));
+
+  // ---- headers and offsets (jcmarker.c: frame header; per scan DHT of the tables it uses, DRI before the first SOS, SOS)
+  std::vector<uint8_t> hdr[10];
   static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
                                  28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61,
                                  54, 47, 55, 62, 63};
-  for (int t = 0; t < 2; t++) { put16(0xFFDB); put16(67); put(t); for (int k = 0; k < 64; k++) put(e->hq.q[t][zz[k]]); }
-  put16(0xFFC2); put16(17); put(8); put16(g.H); put16(g.W); put(3);
-  put(1); put((g.hs << 4) | g.vs); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
-  uint8_t *const file = e->d_out + HDR_AREA;
-  size_t off = 0;
-  bool dri_sent = false;
-  Geom g2 = g; g2.last_strip = 0; g2.mcu_first = 0;     // K6: RSTn numbering restarts in every scan, never an EOI
-  DeviceTables ht;
-  DeviceResult hr;
-  for (int si = 0; si < 10; si++) {
-    const PS &ps = script[si];
-    ScanDesc sd{};
-    sd.kind = ps.Ss == 0 ? (ps.Ah == 0 ? 1 : 2) : (ps.Ah == 0 ? 3 : 4);
-    sd.ncomp = ps.ncomp;
-    for (int i = 0; i < 3; i++) sd.comp[i] = ps.comp[i];
-    sd.Ss = ps.Ss; sd.Se = ps.Se; sd.Al = ps.Al; sd.ri = g.ri;
-    size_t slot;
-    if (ps.ncomp > 1) { sd.bw = g.mcux; sd.bh = g.mcuy; sd.nmcu = (long long)g.mcux * g.mcuy; slot = e->slot_bytes; }
-    else {
-      const int c = ps.comp[0];
-      const int cw = c == 0 ? g.W : (g.W + g.hs - 1) / g.hs, ch = c == 0 ? g.H : (g.H + g.vs - 1) / g.vs;
-      sd.bw = (cw + 7) / 8; sd.bh = (ch + 7) / 8; sd.nmcu = (long long)sd.bw * sd.bh; slot = e->slot_bytes_1;
+  size_t off = 0, data_off[10];
+  for (int i = 0; i < 10; i++) {
+    const mij_encoder::ProgScan &q = e->ps[i];
+    std::vector<uint8_t> &h = hdr[i];
+    auto put = [&](int b) { h.push_back((uint8_t)b); };
+    auto put16 = [&](int v) { put(v >> 8); put(v & 255); };
+    if (i == 0) {
+      put16(0xFFD8);
+      put16(0xFFE0); put16(16); put('J'); put('F'); put('I'); put('F'); put(0); put(1); put(1); put(0); put16(1); put16(1); put(0); put(0);
+      for (int t = 0; t < 2; t++) { put16(0xFFDB); put16(67); put(t); for (int k = 0; k < 64; k++) put(e->hq.q[t][zz[k]]); }
+      put16(0xFFC2); put16(17); put(8); put16(g.H); put16(g.W); put(3);
+      put(1); put((g.hs << 4) | g.vs); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
     }
-    const long long nseg = (sd.nmcu + g.ri - 1) / g.ri;
-    if (sd.kind != 2) {
-      HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
-      HIPCHK(e, launch_prog_encode(g, sd, 1, e->d_coef, e->d_tab, e->d_scratch, slot, e->d_seg_bytes, e->d_seg_ff, e->d_hist, nseg, s));
-      // K3 builds all four tables: give the ones this scan does not use a single count so that they are well formed
-      for (int w = 0; w < 4; w++) {
-        const bool used = sd.kind == 1 ? (w == 0 || w == 2) : (w == (ps.comp[0] ? 3 : 1));
-        if (!used) HIPCHK(e, hipMemcpyAsync(e->d_hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, s));
-      }
-      HIPCHK(e, launch_build_tables(g, e->d_hist, 1, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
-      HIPCHK(e, hipMemcpyAsync(&ht, e->d_tab, sizeof ht, hipMemcpyDeviceToHost, s));
-      HIPCHK(e, hipStreamSynchronize(s));
-    }
-    std::vector<uint8_t> sh;   // DHT(s) of the tables this scan uses, DRI before the first SOS, SOS (jcmarker.c write_scan_header)
-    auto sput = [&](int b) { sh.push_back((uint8_t)b); };
-    auto sput16 = [&](int v) { sput(v >> 8); sput(v & 255); };
+    const DeviceTables &ht = e->h_prog_tab[i];
     auto dht = [&](int w, int tcth) {
       const int nv = (int)ht.nvals[w];
-      sput16(0xFFC4); sput16(19 + nv); sput(tcth);
-      for (int i = 1; i <= 16; i++) sput(ht.bits[w][i]);
-      for (int i = 0; i < nv; i++) sput(ht.vals[w][i]);
+      put16(0xFFC4); put16(19 + nv); put(tcth);
+      for (int k = 1; k <= 16; k++) put(ht.bits[w][k]);
+      for (int k = 0; k < nv; k++) put(ht.vals[w][k]);
     };
-    if (sd.kind == 1) { dht(0, 0x00); dht(2, 0x01); }
-    else if (sd.kind >= 3) dht(ps.comp[0] ? 3 : 1, 0x10 | (ps.comp[0] ? 1 : 0));
-    if (!dri_sent) { sput16(0xFFDD); sput16(4); sput16(g.ri); dri_sent = true; }
-    sput16(0xFFDA); sput16(6 + 2 * ps.ncomp); sput(ps.ncomp);
-    for (int i = 0; i < ps.ncomp; i++) {
-      const int c = ps.comp[i], t = c ? 1 : 0;
-      sput(c + 1);
-      sput(ps.Ss == 0 ? (ps.Ah == 0 ? (t << 4) : 0) : t);   // jcmarker.c emit_sos: only the table kind the scan uses
+    if (q.sd.kind == 1) { dht(0, 0x00); dht(2, 0x01); }
+    else if (q.sd.kind >= 3) dht(q.sd.comp[0] ? 3 : 1, 0x10 | (q.sd.comp[0] ? 1 : 0));
+    if (i == 0) { put16(0xFFDD); put16(4); put16(g.ri); }
+    put16(0xFFDA); put16(6 + 2 * q.sd.ncomp); put(q.sd.ncomp);
+    for (int k = 0; k < q.sd.ncomp; k++) {
+      const int c = q.sd.comp[k], t = c ? 1 : 0;
+      put(c + 1);
+      put(q.sd.Ss == 0 ? (q.Ah == 0 ? (t << 4) : 0) : t);   // jcmarker.c emit_sos: only the table kind the scan uses
     }
-    sput(ps.Ss); sput(ps.Se); sput((ps.Ah << 4) | ps.Al);
-    if (si == 0) sh.insert(sh.begin(), fh.begin(), fh.end());
-    if (off + sh.size() + 2 > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "output buffer too small for the progressive file");
-    HIPCHK(e, hipMemcpyAsync(file + off, sh.data(), sh.size(), hipMemcpyHostToDevice, s));
-    off += sh.size();
-    HIPCHK(e, launch_prog_encode(g, sd, 0, e->d_coef, e->d_tab, e->d_scratch, slot, e->d_seg_bytes, e->d_seg_ff, e->d_hist, nseg, s));
-    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
-    HIPCHK(e, launch_compact(g2, e->d_scratch, slot, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, nseg, file + off, e->capacity - off, e->d_res, s));
-    HIPCHK(e, hipMemcpyAsync(&hr, e->d_res, sizeof hr, hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipStreamSynchronize(s));   // also keeps `sh` alive until its upload is done
-    if (hr.scan_bytes > e->capacity - off) return fail(e, MIJ_ERR_OVERFLOW, "output buffer too small for the progressive file");
-    off += (size_t)hr.scan_bytes - 2;     // K6 ends every interval with RSTn; the last one of a scan has none: overwritten next
+    put(q.sd.Ss); put(q.sd.Se); put((q.Ah << 4) | q.sd.Al);
+    off += h.size();
+    data_off[i] = off;
+    const size_t sb = (size_t)e->h_prog_res[i].scan_bytes;
+    if (sb < 2 || off + sb + 2 > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "output buffer too small for the progressive file");
+    off += sb - 2;                          // K6 ends every interval with RSTn; the last one of a scan has none: overwritten
   }
+  uint8_t *const file = e->d_out + HDR_AREA;
+  Geom g2 = g; g2.last_strip = 0; g2.mcu_first = 0;       // K6: RSTn numbering restarts in every scan, never an EOI
+  // compactions first (each one's trailing RSTn lands on the next scan's header position), then the headers on top
+  for (int i = 0; i < 10; i++) {
+    const mij_encoder::ProgScan &q = e->ps[i];
+    HIPCHK(e, launch_compact(g2, q.scratch, q.slot, q.seg_bytes, q.seg_off, q.chunk_base, q.nseg, file + data_off[i], e->capacity - data_off[i],
+                             q.res, e->prog_stream[i & 3]));
+  }
+  for (int q4 = 0; q4 < 4; q4++) {
+    HIPCHK(e, hipEventRecord(e->prog_ev[q4], e->prog_stream[q4]));
+    HIPCHK(e, hipStreamWaitEvent(s, e->prog_ev[q4], 0));
+  }
+  for (int i = 0; i < 10; i++)
+    HIPCHK(e, hipMemcpyAsync(file + data_off[i] - hdr[i].size(), hdr[i].data(), hdr[i].size(), hipMemcpyHostToDevice, s));
   static const uint8_t eoi[2] = {0xFF, 0xD9};
   HIPCHK(e, hipMemcpyAsync(file + off, eoi, 2, hipMemcpyHostToDevice, s));
   off += 2;
-  HIPCHK(e, hipStreamSynchronize(s));
+  HIPCHK(e, hipStreamSynchronize(s));       // `hdr` lives on this stack frame
   e->h_res->scan_bytes = off; e->h_res->header_bytes = 0; e->h_res->flags = 0;
   e->issued = true;
   return MIJ_OK;

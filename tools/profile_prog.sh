@@ -1,0 +1,6 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_prog
+mkdir -p $out
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out -o prog --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --progressive --steps 3 --warmup 1 --no-cpu-baseline --no-psnr > $out/log.txt 2>&1
+echo "profile rc=$?"

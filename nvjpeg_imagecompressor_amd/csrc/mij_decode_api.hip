@@ -68,7 +68,10 @@ struct Parsed {
 // End of the entropy-coded data that starts at `i`: the next marker that is neither a stuffed FF00 nor RSTn.
 static size_t scan_end(const uint8_t *p, size_t n, size_t i) {
   while (i + 1 < n) {
-    if (p[i] == 0xFF && p[i + 1] != 0x00 && (p[i + 1] & 0xF8) != 0xD0 && p[i + 1] != 0xFF) return i;
+    const uint8_t *f = static_cast<const uint8_t *>(memchr(p + i, 0xFF, n - 1 - i));   // FF bytes are rare: let libc skip to them
+    if (!f) return n;
+    i = (size_t)(f - p);
+    if (p[i + 1] != 0x00 && (p[i + 1] & 0xF8) != 0xD0 && p[i + 1] != 0xFF) return i;
     i++;
   }
   return n;

@@ -25,9 +25,9 @@ from PIL import Image, features  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def pil_encode(img, q, ss, opt, rst):
+def pil_encode(img, q, ss, opt, rst, progressive=False):
     b = io.BytesIO()
-    kw = dict(quality=q, subsampling=ss, optimize=opt)
+    kw = dict(quality=q, subsampling=ss, optimize=opt, progressive=progressive)
     if rst:
         kw["restart_marker_blocks"] = rst
     Image.fromarray(img).save(b, "JPEG", **kw)
@@ -64,6 +64,12 @@ def main():
                     open(os.path.join(GOLD, fn), "wb").write(j)
                     index["cases"].append(dict(file=fn, size=name, css=css, optimize=opt, restart=rst, quality=95,
                                                encoder="libjpeg-turbo", len=len(j), crc32="%08x" % zlib.crc32(j)))
+            for rst in (0, 2):   # progressive (always optimised): the scan script and procedures of libjpeg, whole file
+                j = pil_encode(img, 95, css, True, rst, progressive=True)
+                fn = "turbo_%s_css%d_prog_rst%d.jpg" % (name, css, rst)
+                open(os.path.join(GOLD, fn), "wb").write(j)
+                index["cases"].append(dict(file=fn, size=name, css=css, optimize=True, restart=rst, quality=95, progressive=True,
+                                           encoder="libjpeg-turbo", len=len(j), crc32="%08x" % zlib.crc32(j)))
         for css in (3, 4, 5):
             for rst in (0, 2):
                 j = ijg_encode(img, 95, css, False, rst)

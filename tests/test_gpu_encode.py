@@ -117,3 +117,25 @@ def test_reference_facade(mij, oracle, tmp_path, capsys):
     assert (tmp_path / "o.jpg").read_bytes() == out
     r.deleteCompressEnv()
     assert "Compress Cost time" in capsys.readouterr().out
+
+
+def _golden_cases():
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    idx = json.load(open(os.path.join(gold, "index.json")))
+    return gold, [c for c in idx["cases"] if c["file"] and c["restart"] > 0 and c["encoder"] == "libjpeg-turbo"]
+
+
+@pytest.mark.parametrize("case", _golden_cases()[1], ids=lambda c: c["file"])
+def test_gpu_output_equals_committed_libjpeg_turbo_files(mij, oracle, case):
+    """The HIP path against files written by libjpeg-turbo itself (committed under tests/golden/), whole file, baseline and
+    progressive -- no oracle in between. (Files without DRI cannot be asked of this encoder: the restart interval is its
+    unit of parallelism.)"""
+    import os
+    w, h = map(int, case["size"].split("x"))
+    img = oracle.synth_rgb(w, h)
+    want = open(os.path.join(_golden_cases()[0], case["file"]), "rb").read()
+    with mij.Encoder(w, h, case["quality"], case["optimize"], case["css"], restart_interval=case["restart"],
+                     progressive=bool(case.get("progressive"))) as enc:
+        assert enc.encode_host(img, "rgb") == want

@@ -38,7 +38,10 @@ def test_golden_files(oracle, case):
     img = oracle.synth_rgb(w, h)
     want = open(os.path.join(GOLD, case["file"]), "rb").read()
     assert len(want) == case["len"] and "%08x" % zlib.crc32(want) == case["crc32"]
-    got = oracle.encode(img, case["quality"], case["css"], case["optimize"], case["restart"])
+    if case.get("progressive"):
+        got = oracle.encode_progressive(img, case["quality"], case["css"], case["restart"])
+    else:
+        got = oracle.encode(img, case["quality"], case["css"], case["optimize"], case["restart"])
     if case["encoder"] == "libjpeg-turbo":
         assert got == want                     # whole file, headers included
     else:

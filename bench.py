@@ -106,7 +106,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
     strip = sharded.HipStripEncoder(torch, enc, d_img, args.fmt)
-    enc.enable_timing(not args.progressive)   # the progressive route has no per-stage events (ten scans, host-sequenced)
+    enc.enable_timing(True)
     torch.cuda.synchronize()
 
     copy_gbs = hbm_copy_ceiling(torch, dev) if rank == 0 else None
@@ -114,7 +114,7 @@ def main():
 
     def step(record):
         out = sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
-        if record and not args.progressive:
+        if record:
             for k, v in enc.stage_times().items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
         return out
@@ -155,7 +155,7 @@ def main():
                 stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "frac_of_copy_ceiling": round(gbs / copy_gbs, 4) if copy_gbs else None,
                                  "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
-        if stage_roof:
+        if stage_roof and not args.progressive:
             dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
             traffic, traffic_src = measured_traffic(kname[dom], args, optimize and not args.progressive, world)
             roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

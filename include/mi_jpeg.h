@@ -141,7 +141,8 @@ MIJ_API void mij_host_free(void *ptr);
 
 /* Per-stage device times of the last encode in milliseconds (the reference prints one cudaEvent time,
  * ImageCompressorImpl.cu:289-291): [0] transform [1] statistics [2] table build [3] entropy code [4] scan
- * [5] stuff+compact [6] total. Requires mij_encoder_enable_timing(enc, 1) before the encode. */
+ * [5] stuff+compact [6] total. Requires mij_encoder_enable_timing(enc, 1) before the encode. (Progressive encoders report
+ * the ten scans together under [2] and zeros for [3]..[5].) */
 #define MIJ_NUM_STAGE_TIMES 7
 MIJ_API int mij_encoder_enable_timing(mij_encoder *enc, int on);
 MIJ_API int mij_stage_times(mij_encoder *enc, float ms[MIJ_NUM_STAGE_TIMES]);

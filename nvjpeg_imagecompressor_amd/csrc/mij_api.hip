@@ -466,6 +466,7 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
   static const uint8_t eoi[2] = {0xFF, 0xD9};
   HIPCHK(e, hipMemcpyAsync(file + off, eoi, 2, hipMemcpyHostToDevice, s));
   off += 2;
+  if (e->timed_run) for (int i = 3; i <= 6; i++) HIPCHK(e, hipEventRecord(e->ev[i], s));   // stage [2] = all ten scans, [6] = total
   HIPCHK(e, hipStreamSynchronize(s));       // `hdr` lives on this stack frame
   e->h_res->scan_bytes = off; e->h_res->header_bytes = 0; e->h_res->flags = 0;
   e->issued = true;
@@ -479,7 +480,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   e->last_stream = s;
   const Geom &g = e->g;
-  if (e->p.progressive) { e->timed_run = false; return encode_progressive(e, s); }
+  if (e->p.progressive) return encode_progressive(e, s);
   // Fixed (Annex K) tables and the header do not depend on the image: built once per handle.
   if (e->p.optimized_huffman || !e->static_tables_ready) {
     int rc = run_tail(e, s, true);

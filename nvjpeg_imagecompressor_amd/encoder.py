@@ -233,16 +233,17 @@ class NvjpegCompressRunner:
     """
 
     def __init__(self, width=8320, height=40000, quality=95, optimize=True, css=0, restart_interval=MIJ_RESTART_AUTO,
-                 device=0, verbose=True):
+                 device=0, verbose=True, progressive=False):
         self.width, self.height, self.quality, self.optimize = width, height, quality, optimize
         self.css, self.restart_interval, self.device, self.verbose = css, restart_interval, device, verbose
+        self.progressive = progressive   # the reference's nvJPEG encoding (ImageCompressorImpl.cu:28); default: baseline, the fast path
         self._enc = None
         self._dec = None
 
     def buildCompressEnv(self):
         if self._enc is None:  # a second build is a no-op (the reference leaks here)
             self._enc = Encoder(self.width, self.height, self.quality, self.optimize, self.css, self.restart_interval,
-                                self.device)
+                                self.device, progressive=self.progressive)
             self._enc.enable_timing(True)
 
     def deleteCompressEnv(self):

@@ -66,3 +66,19 @@ def test_progressive_smaller_than_baseline_and_same_pixels(mij, oracle):
 def test_progressive_rejects_strips(mij):
     with pytest.raises(mij.MiJpegError, match="whole images"):
         mij.Encoder(512, 512, 90, True, 0, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)
+
+
+def test_facade_progressive(mij, oracle, capsys):
+    """NvjpegCompressRunner mirror with the reference's encoding (ImageCompressorImpl.cu:28) switched on."""
+    W, H = 208, 120
+    bgr = np.ascontiguousarray(oracle.synth_rgb(W, H)[..., ::-1])
+    r = mij.NvjpegCompressRunner(W, H, 95, True, css=1, verbose=True, progressive=True)
+    r.buildCompressEnv()
+    out, state = r.compress(bgr)
+    assert state == 1 and b"\xff\xc2" in out[:700]
+    assert "Compress Cost time" in capsys.readouterr().out      # the reference's timing line (ImageCompressorImpl.cu:289-291)
+    r.deleteCompressEnv()
+    b = io.BytesIO()
+    Image.fromarray(bgr[..., ::-1]).save(b, "JPEG", quality=95, subsampling=1, progressive=True,
+                                         restart_marker_blocks=mij.Encoder(W, H, 95, True, 1).geometry["restart_interval"])
+    assert out == b.getvalue()

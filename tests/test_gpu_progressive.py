@@ -82,3 +82,20 @@ def test_facade_progressive(mij, oracle, capsys):
     Image.fromarray(bgr[..., ::-1]).save(b, "JPEG", quality=95, subsampling=1, progressive=True,
                                          restart_marker_blocks=mij.Encoder(W, H, 95, True, 1).geometry["restart_interval"])
     assert out == b.getvalue()
+
+
+def test_progressive_eob_run_cap_and_correction_flush(mij, oracle):
+    """Restart intervals long enough for an EOB run to reach 0x7FFF blocks, and noise at q100 for the 937-bit rule."""
+    W, H = 2304, 2048
+    img = np.full((H, W, 3), (120, 200, 33), np.uint8)
+    img[1000:1010, 500:520] = 255
+    with mij.Encoder(W, H, 90, True, 0, restart_interval=65535, progressive=True) as enc:
+        got = enc.encode_host(img, "rgb")
+    assert got == oracle.encode_progressive(img, 90, 0, 65535)
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", quality=90, subsampling=0, progressive=True, restart_marker_blocks=65535)
+    assert got == b.getvalue()
+    noise = np.random.default_rng(5).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    for q in (100, 98):
+        with mij.Encoder(512, 512, q, True, 0, progressive=True) as enc:
+            assert enc.encode_host(noise, "rgb") == oracle.encode_progressive(noise, q, 0, enc.geometry["restart_interval"])

@@ -170,3 +170,15 @@ def test_progressive_with_restart_interval(oracle, ri):
     img = oracle.synth_rgb(176, 120)
     for ss in (0, 1, 2):
         assert oracle.encode_progressive(img, 85, ss, ri) == _pil_progressive(img, 85, ss, restart_marker_blocks=ri)
+
+
+def test_progressive_flush_rules(oracle):
+    """The two flush rules of the EOB-run machinery: a run is cut at 0x7FFF blocks (large flat image, no DRI) and when more
+    than 937 correction bits are waiting behind it (noise at q98-100)."""
+    img = np.full((2048, 2304, 3), (120, 200, 33), np.uint8)
+    img[1000:1010, 500:520] = 255
+    for ss in (0, 2):
+        assert oracle.encode_progressive(img, 90, ss) == _pil_progressive(img, 90, ss)
+    noise = np.random.default_rng(5).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    for q in (100, 98):
+        assert oracle.encode_progressive(noise, q, 0) == _pil_progressive(noise, q, 0)

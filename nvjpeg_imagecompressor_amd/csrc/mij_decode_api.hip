@@ -26,6 +26,12 @@ struct mij_decoder {
   unsigned long long *d_chunk_cnt = nullptr, *d_chunk_base = nullptr; size_t chunk_cap = 0;
   uint32_t *d_flags = nullptr;    // [0] scratch for the scan kernel, [1] Huffman decode errors, [2] "a synchronisation pass changed a state"
   uint8_t *d_par_ws = nullptr; size_t par_ws_cap = 0;   // workspace of the parallel baseline decoder
+  // generic route: independent scans run concurrently, each with its own restart-position workspace
+  unsigned long long *d_scan_ws = nullptr; size_t scan_ws_cap = 0;
+  hipStream_t aux[4]{};
+  std::vector<hipEvent_t> scan_ev;
+  hipEvent_t ev_ready{};
+  bool aux_ok = false;
   int sync_passes = 0;
   DeviceResult *d_res = nullptr;
   uint8_t *d_out = nullptr; size_t out_cap = 0;
@@ -254,7 +260,9 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws);
+  if (d->aux_ok) { for (auto &q : d->aux) (void)hipStreamDestroy(q); (void)hipEventDestroy(d->ev_ready); }
+  for (auto &v : d->scan_ev) (void)hipEventDestroy(v);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   delete d;
 }
@@ -351,14 +359,50 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     DHIP(d, hipMemcpyAsync(d->d_tabs, tabs.data(), tabs.size() * sizeof(DecTables), hipMemcpyHostToDevice, s));
     DHIP(d, hipMemsetAsync(d->d_coef, 0, ncoef * sizeof(int16_t), s));
     DHIP(d, hipStreamSynchronize(s));   // `tabs` lives on this stack frame
+    // Scans that touch disjoint coefficients (different components, or disjoint spectral bands of one component) are
+    // independent: each runs on one of four streams after the earlier scans it overlaps with. A refinement scan thus
+    // waits for the first scan of its band, while e.g. the chroma scans proceed next to the luma ones.
+    if (!d->aux_ok) {
+      for (auto &q : d->aux) DHIP(d, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+      DHIP(d, hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+      d->aux_ok = true;
+    }
+    while (d->scan_ev.size() < ps.scans.size()) {
+      hipEvent_t ev;
+      DHIP(d, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      d->scan_ev.push_back(ev);
+    }
+    // per-scan workspace: restart positions (ns + 1) and two chunk-count arrays
+    std::vector<size_t> o_seg(ps.scans.size()), o_cnt(ps.scans.size()), o_base(ps.scans.size());
+    size_t words = 0;
     for (size_t i = 0; i < ps.scans.size(); i++) {
       const ScanInfo &sc = ps.scans[i];
+      const size_t ns = sc.sd.ri > 0 ? (size_t)((sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri) : 1, nch = (sc.len + 16383) / 16384 + 1;
+      o_seg[i] = words; words += ns + 1;
+      o_cnt[i] = words; words += nch;
+      o_base[i] = words; words += nch + 1;
+    }
+    if ((rc = ensure(d, d->d_scan_ws, d->scan_ws_cap, words))) return rc;
+    DHIP(d, hipEventRecord(d->ev_ready, s));
+    for (auto &q : d->aux) DHIP(d, hipStreamWaitEvent(q, d->ev_ready, 0));
+    for (size_t i = 0; i < ps.scans.size(); i++) {
+      const ScanInfo &sc = ps.scans[i];
+      hipStream_t q = d->aux[i & 3];
+      for (size_t j = 0; j < i; j++) {
+        const ScanDesc &a = ps.scans[j].sd, &b = sc.sd;
+        bool comp = false;
+        for (int x = 0; x < a.ncomp; x++) for (int y = 0; y < b.ncomp; y++) comp |= a.comp[x] == b.comp[y];
+        if (comp && a.Ss <= b.Se && b.Ss <= a.Se && (j & 3) != (i & 3)) DHIP(d, hipStreamWaitEvent(q, d->scan_ev[j], 0));
+      }
       const uint8_t *base = d->d_scan + (sc.off - data_off);
       const long long ns = sc.sd.ri > 0 ? (sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri : 1;
-      if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, ns, d->d_flags, d->d_res, s));
-      else DHIP(d, hipMemsetAsync(d->d_seg_pos, 0, sizeof(unsigned long long), s));
-      DHIP(d, launch_scan_decode(g, sc.sd, base, sc.len, d->d_seg_pos, ns, d->d_tabs + i, d->d_coef, d->d_flags + 1, s));
+      unsigned long long *seg = d->d_scan_ws + o_seg[i];
+      if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], seg, ns, d->d_flags, d->d_res, q));
+      else DHIP(d, hipMemsetAsync(seg, 0, sizeof(unsigned long long), q));
+      DHIP(d, launch_scan_decode(g, sc.sd, base, sc.len, seg, ns, d->d_tabs + i, d->d_coef, d->d_flags + 1, q));
+      DHIP(d, hipEventRecord(d->scan_ev[i], q));
     }
+    for (size_t i = 0; i < ps.scans.size(); i++) DHIP(d, hipStreamWaitEvent(s, d->scan_ev[i], 0));
     d_final = d->d_tabs + (ps.scans.size() - 1);
   }
   uint8_t *py = d->d_planes, *pcb = py + ysz, *pcr = pcb + csz;

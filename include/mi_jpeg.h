@@ -186,6 +186,17 @@ MIJ_API int mij_decode_host(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_b
  * mode +1: out = clip(a + b - 128)  (reconstruction from decoded a and decoded residual b).  n = number of bytes. */
 MIJ_API int mij_residual_device(const void *d_a, const void *d_b, void *d_out, size_t n, int mode, void *stream);
 
+/* The whole two-layer scheme in one call each way (host memory in, host memory out; whole images, not strips):
+ *   encode:  J1 = enc(I);  D = dec(J1);  R = clip(I - D + 128);  J2 = enc(R)          (same quality / sampling for both layers)
+ *   decode:  I' = clip(dec(J1) + dec(J2) - 128)
+ * `primary` / `secondary` are caller buffers; *primary_bytes / *secondary_bytes hold their capacities on entry and the
+ * file sizes on return (MIJ_ERR_OVERFLOW, with the required sizes stored, if either is too small). */
+MIJ_API int mij_secondary_encode_host(mij_encoder *enc, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride,
+                                      int input_format, uint8_t *primary, size_t *primary_bytes, uint8_t *secondary,
+                                      size_t *secondary_bytes);
+MIJ_API int mij_secondary_decode_host(mij_decoder *dec, const uint8_t *primary, size_t primary_bytes, const uint8_t *secondary,
+                                      size_t secondary_bytes, uint8_t *dst, size_t pitch, int output_format, int *width, int *height);
+
 /* Bench utility: fill device memory with rows [y0, y0+rows) of the SURVEY.md 8(d) synthetic image
  * (RGB or BGR interleaved). */
 MIJ_API int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream);

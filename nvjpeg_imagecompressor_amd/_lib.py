@@ -24,6 +24,7 @@ EXPORTS = (
     "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
     "mij_synth_image_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
     "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device", "mij_host_alloc", "mij_host_free",
+    "mij_secondary_encode_host", "mij_secondary_decode_host",
 )
 
 
@@ -106,6 +107,8 @@ def load():
     L.mij_encode_result.argtypes = [vp, C.POINTER(Result)]
     L.mij_retrieve_bitstream.argtypes = [vp, vp, C.POINTER(sz)]
     L.mij_encode_host.argtypes = [vp, vp, sz, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    L.mij_secondary_encode_host.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp, C.POINTER(sz), vp, C.POINTER(sz)]
+    L.mij_secondary_decode_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mij_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.mij_host_free.argtypes = [vp]
     L.mij_host_free.restype = None

@@ -112,6 +112,46 @@ cv::Mat NvjpegCompressRunner::decode(std::string image_path, int *run_state) {
   return result;
 }
 
+std::vector<unsigned char> NvjpegCompressRunner::secondaryCompress(cv::Mat image, std::vector<unsigned char> &primary, int *run_state) {
+  std::vector<unsigned char> secondary;
+  primary.clear();
+  if (!compressor->enc || !compressor->dec) {
+    std::cerr << "[ERROR] secondaryCompress() needs buildCompressEnv() and buildDecodeEnv()" << std::endl;
+  } else if (image.empty() || image.type() != CV_8UC3 || image.cols != compressor->p.width || image.rows != compressor->p.height) {
+    std::cerr << "[ERROR] secondaryCompress(): image must be CV_8UC3 " << compressor->p.width << "x" << compressor->p.height << std::endl;
+  } else {
+    const size_t cap = (size_t)image.cols * image.rows * 3 + 65536;     // a JPEG at any quality stays below the raw size + headers
+    primary.resize(cap); secondary.resize(cap);
+    size_t n1 = cap, n2 = cap;
+    if (mij_secondary_encode_host(compressor->enc, compressor->dec, image.ptr<unsigned char>(0), image.step, 0, MIJ_INPUT_BGRI, primary.data(),
+                                  &n1, secondary.data(), &n2) == MIJ_OK) {
+      primary.resize(n1); secondary.resize(n2);
+    } else {
+      compressor->err = mij_last_error(compressor->enc);
+      primary.clear(); secondary.clear();
+    }
+  }
+  if (run_state) *run_state = secondary.empty() ? 0 : 1;
+  return secondary;
+}
+
+cv::Mat NvjpegCompressRunner::secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int *run_state) {
+  cv::Mat result;
+  int w = 0, h = 0;
+  if (!compressor->dec) {
+    std::cerr << "[ERROR] secondaryDecode() called before buildDecodeEnv() succeeded" << std::endl;
+  } else if (mij_decode_info(primary.data(), primary.size(), &w, &h, nullptr, nullptr) == MIJ_OK) {
+    cv::Mat m(h, w, CV_8UC3);
+    if (mij_secondary_decode_host(compressor->dec, primary.data(), primary.size(), secondary.data(), secondary.size(), m.ptr<unsigned char>(0),
+                                  m.step, MIJ_INPUT_BGRI, &w, &h) == MIJ_OK)
+      result = m;
+    else
+      compressor->err = mij_decoder_last_error(compressor->dec);
+  }
+  if (run_state) *run_state = result.empty() ? 0 : 1;
+  return result;
+}
+
 void NvjpegCompressRunner::save(std::string save_path, std::vector<unsigned char> obuffer) {
   try {
     std::ofstream outputFile(save_path, std::ios::out | std::ios::binary);

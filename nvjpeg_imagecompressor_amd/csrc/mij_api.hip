@@ -54,6 +54,8 @@ struct mij_encoder {
   size_t d_src_bytes = 0;
   uint8_t *h_out = nullptr;
   size_t h_out_cap = 0;
+  uint8_t *d_sec = nullptr;   // secondary compression: decoded first layer and residual, same layout as d_src
+  size_t d_sec_bytes = 0;
   hipStream_t s_copy = nullptr, s_work = nullptr;   // mij_encode_host: upload stream / kernel stream
   hipEvent_t ev_chunk[2]{};                          // "chunk i has landed" (ping-pong)
   bool host_streams = false;
@@ -150,7 +152,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   if (e->last_stream || e->issued) (void)hipStreamSynchronize(e->last_stream);
   (void)hipFree(e->d_qt); (void)hipFree(e->d_tab); (void)hipFree(e->d_hist_own); (void)hipFree(e->d_coef); (void)hipFree(e->d_dc);
   (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off); (void)hipFree(e->d_chunk_total); (void)hipFree(e->d_chunk_base); (void)hipFree(e->d_ovf);
-  (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src);
+  (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src); (void)hipFree(e->d_sec);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->ev_ok) for (auto &v : e->ev) (void)hipEventDestroy(v);
@@ -641,6 +643,42 @@ int mij_encode_host(mij_encoder *e, const uint8_t *src, size_t pitch, size_t pla
   *jpeg = e->h_out;
   *jpeg_bytes = r.file_bytes;
   return MIJ_OK;
+}
+
+// Secondary ("difference map") compression end to end (reference README.md:8; definition SURVEY.md 8a A9).
+int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt,
+                              uint8_t *primary, size_t *primary_bytes, uint8_t *secondary, size_t *secondary_bytes) {
+  if (!e || !dec || !src || !primary || !primary_bytes || !secondary || !secondary_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  const Geom &g = e->g;
+  if (g.mcu_first != 0 || !g.last_strip) return fail(e, MIJ_ERR_INVALID_ARG, "secondary compression works on whole images");
+  const uint8_t *j1 = nullptr; size_t n1 = 0;
+  int rc = mij_encode_host(e, src, pitch, plane_stride, fmt, &j1, &n1);      // J1; the image stays in e->d_src
+  if (rc) return rc;
+  const size_t cap1 = *primary_bytes, cap2 = *secondary_bytes;
+  *primary_bytes = n1;
+  if (n1 > cap1) { *secondary_bytes = 0; return fail(e, MIJ_ERR_OVERFLOW, "primary buffer too small"); }
+  memcpy(primary, j1, n1);
+  const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
+  const size_t bytes = interleaved ? pitch * (size_t)g.H : plane_stride * 2 + pitch * (size_t)g.H;
+  if (2 * bytes > e->d_sec_bytes) {
+    (void)hipFree(e->d_sec); e->d_sec = nullptr; e->d_sec_bytes = 0;
+    HIPCHK(e, hipMalloc(&e->d_sec, 2 * bytes));
+    e->d_sec_bytes = 2 * bytes;
+  }
+  uint8_t *d_dec = e->d_sec, *d_res = e->d_sec + bytes;
+  rc = mij_decode_device(dec, primary, n1, d_dec, pitch, plane_stride, fmt, nullptr);   // D = dec(J1), same layout as the input
+  if (!rc) rc = mij_decode_sync(dec, nullptr);
+  if (rc) return fail(e, rc, mij_decoder_last_error(dec));
+  rc = mij_residual_device(e->d_src, d_dec, d_res, bytes, -1, nullptr);                 // R = clip(I - D + 128)
+  if (rc) return fail(e, rc, "residual kernel");
+  rc = mij_encode_device(e, d_res, pitch, plane_stride, fmt, nullptr);                  // J2 = enc(R)
+  if (rc) return rc;
+  size_t n2 = 0;
+  rc = mij_retrieve_bitstream(e, nullptr, &n2);
+  if (rc) return rc;
+  *secondary_bytes = n2;
+  if (n2 > cap2) return fail(e, MIJ_ERR_OVERFLOW, "secondary buffer too small");
+  return mij_retrieve_bitstream(e, secondary, &n2);
 }
 
 int mij_stage_times(mij_encoder *e, float ms[MIJ_NUM_STAGE_TIMES]) {

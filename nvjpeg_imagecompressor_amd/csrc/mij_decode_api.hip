@@ -35,6 +35,7 @@ struct mij_decoder {
   int sync_passes = 0;
   DeviceResult *d_res = nullptr;
   uint8_t *d_out = nullptr; size_t out_cap = 0;
+  uint8_t *d_out2 = nullptr; size_t out2_cap = 0;     // second layer of a secondary-compression pair
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0{}, ev1{};
   bool ev_ok = false, issued = false;
@@ -260,7 +261,7 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws);
   if (d->aux_ok) { for (auto &q : d->aux) (void)hipStreamDestroy(q); (void)hipEventDestroy(d->ev_ready); }
   for (auto &v : d->scan_ev) (void)hipEventDestroy(v);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
@@ -443,6 +444,33 @@ int mij_decode_host(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, uint
   if (rc) return rc;
   if (interleaved) DHIP(d, hipMemcpy2D(dst, pitch, d->d_out, row, row, (size_t)h, hipMemcpyDeviceToHost));
   else DHIP(d, hipMemcpy2D(dst, pitch, d->d_out, row, row, (size_t)h * 3, hipMemcpyDeviceToHost));
+  if (width) *width = w;
+  if (height) *height = h;
+  return MIJ_OK;
+}
+
+int mij_secondary_decode_host(mij_decoder *d, const uint8_t *primary, size_t primary_bytes, const uint8_t *secondary, size_t secondary_bytes,
+                              uint8_t *dst, size_t pitch, int output_format, int *width, int *height) {
+  if (!d || !primary || !secondary || !dst) return dfail(d, MIJ_ERR_INVALID_ARG, "null argument");
+  int w = 0, h = 0, w2 = 0, h2 = 0;
+  int rc = mij_decode_info(primary, primary_bytes, &w, &h, nullptr, nullptr);
+  if (!rc) rc = mij_decode_info(secondary, secondary_bytes, &w2, &h2, nullptr, nullptr);
+  if (rc) return dfail(d, rc, g_dec_err.c_str());
+  if (w != w2 || h != h2) return dfail(d, MIJ_ERR_BAD_STREAM, "the two layers have different dimensions");
+  const bool interleaved = output_format == MIJ_INPUT_BGRI || output_format == MIJ_INPUT_RGBI;
+  if (!interleaved && output_format != MIJ_INPUT_BGR && output_format != MIJ_INPUT_RGB) return dfail(d, MIJ_ERR_INVALID_ARG, "unknown output format");
+  const size_t row = (size_t)w * (interleaved ? 3 : 1);
+  if (pitch < row) return dfail(d, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
+  const size_t bytes = row * h * (interleaved ? 1 : 3);
+  DHIP(d, hipSetDevice(d->device));
+  if ((rc = ensure(d, d->d_out, d->out_cap, bytes)) || (rc = ensure(d, d->d_out2, d->out2_cap, bytes))) return rc;
+  rc = mij_decode_device(d, primary, primary_bytes, d->d_out, row, row * h, output_format, nullptr);
+  if (!rc) rc = mij_decode_sync(d, nullptr);
+  if (!rc) rc = mij_decode_device(d, secondary, secondary_bytes, d->d_out2, row, row * h, output_format, nullptr);
+  if (!rc) rc = mij_decode_sync(d, nullptr);
+  if (rc) return rc;
+  if (launch_residual(d->d_out, d->d_out2, d->d_out, bytes, +1, nullptr) != hipSuccess) return dfail(d, MIJ_ERR_HIP, "residual kernel");   // I' = clip(D + R' - 128)
+  DHIP(d, hipMemcpy2D(dst, pitch, d->d_out, row, row, (size_t)h * (interleaved ? 1 : 3), hipMemcpyDeviceToHost));
   if (width) *width = w;
   if (height) *height = h;
   return MIJ_OK;

@@ -301,6 +301,44 @@ class NvjpegCompressRunner:
             print("[INFO] NvjpegCompressRunner Compress Func Cost Time : %d ms" % int((time.perf_counter() - t0) * 1e3))
         return out, (0 if not out else 1)
 
+    def secondaryCompress(self, image):
+        """Secondary ("difference map") compression, reference README.md:8: returns (primary, secondary, run_state) where
+        primary = JPEG(image) and secondary = JPEG(clip(image - decode(primary) + 128)). Needs both environments."""
+        try:
+            if self._enc is None or self._dec is None:
+                raise MiJpegError("secondaryCompress() needs buildCompressEnv() and buildDecodeEnv()")
+            image = np.ascontiguousarray(image, np.uint8)
+            if image.shape != (self.height, self.width, 3):
+                raise MiJpegError("image must be uint8 %dx%dx3" % (self.height, self.width))
+            cap = image.size + 65536
+            b1, b2 = np.empty(cap, np.uint8), np.empty(cap, np.uint8)
+            n1, n2 = C.c_size_t(cap), C.c_size_t(cap)
+            L = self._enc._L
+            _lib.check(L.mij_secondary_encode_host(self._enc._h, self._dec._h, image.ctypes.data, self.width * 3, 0, _FMT["bgr"],
+                                                   b1.ctypes.data, C.byref(n1), b2.ctypes.data, C.byref(n2)), self._enc._h,
+                       "mij_secondary_encode_host")
+            return b1[:n1.value].tobytes(), b2[:n2.value].tobytes(), 1
+        except MiJpegError as e:
+            print("[ERROR] Exception caught: %s" % e)
+            return b"", b"", 0
+
+    def secondaryDecode(self, primary, secondary):
+        """(primary, secondary) -> (H x W x 3 uint8 BGR, run_state): clip(decode(primary) + decode(secondary) - 128)."""
+        try:
+            if self._dec is None:
+                raise MiJpegError("secondaryDecode() before buildDecodeEnv()")
+            inf = Decoder.info(primary)
+            out = np.empty((inf["height"], inf["width"], 3), np.uint8)
+            p1, p2 = np.frombuffer(primary, np.uint8), np.frombuffer(secondary, np.uint8)
+            w, h = C.c_int(), C.c_int()
+            self._dec._check(self._dec._L.mij_secondary_decode_host(self._dec._h, p1.ctypes.data, len(primary), p2.ctypes.data, len(secondary),
+                                                                    out.ctypes.data, inf["width"] * 3, _FMT["bgr"], C.byref(w), C.byref(h)),
+                             "mij_secondary_decode_host")
+            return out, 1
+        except MiJpegError as e:
+            print("[ERROR] Exception caught: %s" % e)
+            return None, 0
+
     def save(self, save_path, obuffer):
         try:
             with open(save_path, "wb") as f:

@@ -129,3 +129,30 @@ def test_fullsize_decode_and_secondary_compression(mij, oracle):
     assert p2 > p1 + 0.02                    # the second layer improves the reconstruction (little at 4:2:2: the residual's
                                              # chroma is subsampled again; the README gives no figure to pin this to)
     print("secondary compression: J1 %d B (%.2f dB), J2 %d B, combined %.2f dB, decode %.2f ms" % (len(j1), p1, len(j2), p2, ms1))
+
+
+def test_secondary_compression_end_to_end(mij, oracle):
+    """mij_secondary_encode_host / _decode_host through the facade mirror (reference README.md:8): the pair
+    reproduces exactly what the documented definition gives when put together from the single-layer calls and Pillow."""
+    W, H = 416, 240
+    rgb = oracle.synth_rgb(W, H)
+    bgr = np.ascontiguousarray(rgb[..., ::-1])
+    r = mij.NvjpegCompressRunner(W, H, 90, True, css=0, verbose=False)
+    r.buildCompressEnv(); r.buildDecodeEnv()
+    j1, j2, state = r.secondaryCompress(bgr)
+    assert state == 1
+    # definition, spelled out with the stock decoder
+    ri = mij.Encoder(W, H, 90, True, 0).geometry["restart_interval"]
+    assert j1 == oracle.encode(rgb, 90, 0, True, ri)
+    d1 = _pil_dec(j1).astype(np.int32)
+    resid = np.clip(rgb.astype(np.int32) - d1 + 128, 0, 255).astype(np.uint8)
+    assert j2 == oracle.encode(resid, 90, 0, True, ri)
+    want = np.clip(d1 + _pil_dec(j2).astype(np.int32) - 128, 0, 255).astype(np.uint8)
+    got, state = r.secondaryDecode(j1, j2)
+    assert state == 1 and np.array_equal(got[..., ::-1], want)
+    # (re-coding the residual at the SAME quality barely moves the PSNR -- the error is below the quantiser step; the
+    # README gives no figure to pin the scheme's benefit to, only that it exists)
+    assert abs(oracle.psnr(rgb, want) - oracle.psnr(rgb, d1.astype(np.uint8))) < 0.2
+    none, state = r.secondaryDecode(j1, j2[:100])
+    assert none is None and state == 0
+    r.deleteCompressEnv(); r.deleteDecodeEnv()

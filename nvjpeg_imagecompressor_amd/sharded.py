@@ -57,13 +57,32 @@ class HipStripEncoder:
         r = self.enc.result()    # waits for this strip; sizes are now known on the host
         self.last_result = r
         dev = self.d_img.device
-        return (device_bytes(self.torch, r["d_buffer"] + r["header_offset"], r["header_bytes"], dev),
-                device_bytes(self.torch, r["d_buffer"] + r["scan_offset"], r["scan_bytes"], dev))
+        return (self._view(r["d_buffer"] + r["header_offset"], r["header_bytes"], dev),
+                self._view(r["d_buffer"] + r["scan_offset"], r["scan_bytes"], dev))
 
+    def encode_whole(self, stream=0):
+        """Single-rank shortcut: entropy-code and return the complete file (header and scan sit back to back in the
+        encoder's buffer), without building the separate header / scan views nobody would read."""
+        self.enc.entropy(stream)
+        r = self.enc.result()
+        self.last_result = r
+        return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device)
 
     def whole_file(self):
         r = self.last_result
-        return device_bytes(self.torch, r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device)
+        return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device)
+
+    def _view(self, ptr, nbytes, dev):
+        # wrapping device memory in a tensor costs ~10 us of host time; the same (address, size) recurs on every step of a
+        # steady-state loop, so keep the last few views
+        cache = self.__dict__.setdefault("_views", {})
+        key = (int(ptr), int(nbytes))
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 8:
+                cache.clear()
+            t = cache[key] = device_bytes(self.torch, ptr, nbytes, dev)
+        return t
 
 
 def device_bytes(torch, ptr, nbytes, device):
@@ -83,10 +102,10 @@ def encode_step(torch, dist, strip_encoder, optimize, out_cache, stream=0):
     hist = strip_encoder.transform(stream)
     if world > 1 and optimize:
         dist.all_reduce(hist)                      # the only collective on the data path before entropy coding
+    if world == 1 and hasattr(strip_encoder, "encode_whole"):
+        return strip_encoder.encode_whole(stream)
     header, scan = strip_encoder.entropy(stream)
     if world == 1:
-        if hasattr(strip_encoder, "whole_file"):   # header and scan already sit back to back in the encoder's buffer
-            return strip_encoder.whole_file()
         n = header.numel() + scan.numel()
         buf = _buffer(torch, out_cache, n, scan.device)
         buf[:header.numel()].copy_(header)

@@ -207,6 +207,7 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
   g.last_strip = (row0 + rows == g.mcuy);
   if (!g.last_strip && (g.mcu_count % ri)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not end on a restart-interval boundary"); }
   g.y_origin = row0 * 8 * vs;
+  geom_finish(g);
   if (p->progressive && (row0 != 0 || rows != g.mcuy)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "progressive output is for whole images (no strips)"); }
   e->nseg = (g.mcu_count + ri - 1) / ri;
   e->coef_count = (size_t)g.mcu_count * g.bpm * 64;

@@ -308,6 +308,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   g.mcux = (g.W + 8 * g.hs - 1) / (8 * g.hs); g.mcuy = (g.H + 8 * g.vs - 1) / (8 * g.vs);
   g.mcu_first = 0; g.mcu_count = (long long)g.mcux * g.mcuy; g.last_strip = 1;
   g.ri = ps.ri > 0 ? ps.ri : (int)std::min<long long>(g.mcu_count, 0x7FFFFFFF);   // no DRI: one interval = one lane (slow)
+  geom_finish(g);
   const size_t ncoef = (size_t)g.mcu_count * g.bpm * 64;
   const size_t ysz = (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8, csz = (size_t)g.mcux * 8 * g.mcuy * 8;
   // entropy-coded bytes of all scans, from the first scan's data to the end of the last one's

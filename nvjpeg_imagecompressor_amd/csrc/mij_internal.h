@@ -54,7 +54,16 @@ struct Geom {
   int y_origin;           // image row of the strip's first source row
   int last_strip;
   int quality;
+  // derived (geom_finish): 64-bit integer division costs ~300 instructions on this hardware, so the kernels divide by
+  // multiplication (k_common.inc div_magic) or step incrementally
+  uint32_t mcux_magic;    // floor(2^32 / mcux), saturated
+  uint32_t seg0;          // index of the strip's first restart interval = mcu_first / ri
 };
+inline void geom_finish(Geom &g) {
+  const unsigned long long m = 0x100000000ull / (unsigned)g.mcux;
+  g.mcux_magic = (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m);
+  g.seg0 = (uint32_t)(g.mcu_first / g.ri);
+}
 
 struct TransformArgs {
   const uint8_t *src; size_t pitch, plane_stride;

@@ -13,10 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
-    "staged_h3": {},
-    "direct_h4": {"MIJ_K1_STAGED": 0, "MIJ_HIST_COPIES": 4},
-    "direct_h3": {"MIJ_K1_STAGED": 0},
-    "staged_h2": {"MIJ_HIST_COPIES": 2},
+    "default": {},
+    "noatomic": {"MIJ_K1_STATMODE": 1},
+    "waste_only": {"MIJ_K1_STATMODE": 2},
+    "copies2": {"MIJ_HIST_COPIES": 2},
+    "copies4_w2": {"MIJ_HIST_COPIES": 4, "MIJ_K1_WAVES": 2},
 }
 
 

@@ -162,6 +162,11 @@ def main():
                         "frac": stage_roof[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
                         "note": "avg launch duration from hipEvents on the kernels' stream over the timed steps"}
+            if dom == "transform" and optimize:
+                # K1 also takes the AC statistics (SURVEY 8d stage B, a separate 2(1+f) B/px read in an unfused design);
+                # against stage A + B's algorithmic bytes, as SURVEY 8d prescribes for a fused kernel:
+                fused = (bpp["transform"] + bpp_stage_b(args.css)) * strip_px / (stage_roof[dom]["ms"] * 1e-3) / 1e9
+                roofline["frac_vs_stage_A_plus_B_bytes"] = round(fused / HBM_PEAK_GBS, 4)
         else:   # --progressive: twenty lane-per-interval passes sequenced by the host; not a roofline-shaped workload
             roofline = {"bound": "hbm", "kernel": "k_prog_encode", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         out = {
@@ -188,6 +193,12 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bpp_stage_b(css):
+    """Algorithmic bytes per pixel of a separate histogram pass (SURVEY 8d stage B): read the int16 coefficients once."""
+    f = {"444": 2.0, "422": 1.0, "440": 1.0, "420": 0.5, "411": 0.5, "410": 0.25}[css]
+    return 2.0 * (1.0 + f)
 
 
 def hbm_copy_ceiling(torch, dev):

@@ -12,12 +12,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
-VARIANTS = {
+VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default" is what ships
     "default": {},
-    "noatomic": {"MIJ_K1_STATMODE": 1},
-    "waste_only": {"MIJ_K1_STATMODE": 2},
+    "direct_stores": {"MIJ_K1_STAGED": 0},
     "copies2": {"MIJ_HIST_COPIES": 2},
-    "copies4_w2": {"MIJ_HIST_COPIES": 4, "MIJ_K1_WAVES": 2},
+    "no_atomics": {"MIJ_K1_STATMODE": 1},
+    "predicated_atomics": {"MIJ_K1_STATMODE": 3},
 }
 
 

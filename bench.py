@@ -112,11 +112,40 @@ def main():
     copy_gbs = hbm_copy_ceiling(torch, dev) if rank == 0 else None
     cache, stage_acc = {}, {}
 
-    def step(record):
-        out = sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+    # One GPU: two encoder handles alternate on the stream, so image i+1's kernels are already queued while the host
+    # collects image i's result (size, stage times). Every step still produces a complete file inside the timed region;
+    # what disappears is the GPU idling during the host's round trip (~35 us of a 1.7 ms step).
+    pipelined = world == 1 and not args.progressive
+    strips = [strip]
+    if pipelined:
+        enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, local_rank, args.fmt)
+        enc2.enable_timing(True)
+        strips.append(sharded.HipStripEncoder(torch, enc2, d_img, args.fmt))
+    state = {"i": 0, "pending": None}
+
+    def collect(record):
+        s_prev = state["pending"]
+        state["pending"] = None
+        if s_prev is None:
+            return None
+        out = s_prev.finish_whole()
         if record:
-            for k, v in enc.stage_times().items():
+            for k, v in s_prev.enc.stage_times().items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
+        return out
+
+    def step(record):
+        if not pipelined:
+            out = sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+            if record:
+                for k, v in enc.stage_times().items():
+                    stage_acc[k] = stage_acc.get(k, 0.0) + v
+            return out
+        cur = strips[state["i"] & 1]
+        state["i"] += 1
+        cur.issue_whole(torch.cuda.current_stream().cuda_stream)
+        out = collect(record)          # the previous image, while this one runs
+        state["pending"] = cur
         return out
 
     def fence():
@@ -127,10 +156,13 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    collect(False)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         jpeg_t = step(True)
+    if pipelined:
+        jpeg_t = collect(True)         # the last image of the timed region
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -177,7 +209,8 @@ def main():
             "config": {"workload": "%dx%d RGB8 (%s interleaved, device resident) -> %s JFIF, q%d, 4:%s:%s, %s Huffman, "
                                    "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
-                       "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"]},
+                       "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
+                       "images_in_flight": 2 if pipelined else 1},
             "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
             "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None, "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }
@@ -190,6 +223,8 @@ def main():
                 out["cpu_libjpeg_turbo"] = dict(cb["turbo"], impl="libjpeg-turbo 3.1.4.1 via Pillow")
         print(json.dumps(out), flush=True)
     enc.close()
+    if pipelined:
+        enc2.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -60,9 +60,11 @@ struct mij_encoder {
   hipEvent_t ev_chunk[2]{};                          // "chunk i has landed" (ping-pong)
   bool host_streams = false;
   hipEvent_t ev[8]{};
+  hipEvent_t ev_done{};      // recorded behind the result copy: mij_encode_result waits for THIS encode only, so that a caller
+                             // who alternates two handles on one stream keeps the GPU busy while it collects a result
   bool ev_ok = false, timing = false, timed_run = false;
   float ms[MIJ_NUM_STAGE_TIMES]{};
-  bool transformed = false, issued = false, static_tables_ready = false;
+  bool transformed = false, issued = false, static_tables_ready = false, wait_event = false;
   hipStream_t last_stream = nullptr;
 };
 
@@ -155,7 +157,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src); (void)hipFree(e->d_sec);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
-  if (e->ev_ok) for (auto &v : e->ev) (void)hipEventDestroy(v);
+  if (e->ev_ok) { for (auto &v : e->ev) (void)hipEventDestroy(v); (void)hipEventDestroy(e->ev_done); }
   (void)hipFree(e->d_prog);
   if (e->h_prog_tab) (void)hipHostFree(e->h_prog_tab);
   if (e->h_prog_res) (void)hipHostFree(e->h_prog_res);
@@ -283,6 +285,7 @@ int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
     e->prog_streams = true;
   }
   for (auto &v : e->ev) CRCHK(hipEventCreate(&v));
+  CRCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
   e->ev_ok = true;
 #undef CRCHK
   *out = e;
@@ -499,7 +502,9 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
                            e->capacity, e->d_res, s));
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[6], s));
   HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipEventRecord(e->ev_done, s));
   e->issued = true;
+  e->wait_event = true;
   return MIJ_OK;
 }
 
@@ -513,7 +518,8 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
   if (!e || !o) return MIJ_ERR_INVALID_ARG;
   if (!e->issued) return fail(e, MIJ_ERR_NOT_READY, "no encode has been issued on this handle");
   HIPCHK(e, hipSetDevice(e->p.device));
-  HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  if (e->wait_event) HIPCHK(e, hipEventSynchronize(e->ev_done));   // this encode's work only (later work on the stream may still run)
+  else HIPCHK(e, hipStreamSynchronize(e->last_stream));
   if (e->h_res->flags & 1u) {
     // Some block needed more than a fast-path strip (768 bits): the fast encoder left those intervals marked; code them
     // with the roomy instantiation, then redo scan + compaction.

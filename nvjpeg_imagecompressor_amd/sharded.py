@@ -68,6 +68,17 @@ class HipStripEncoder:
         self.last_result = r
         return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device)
 
+    def issue_whole(self, stream=0):
+        """Single-rank, two handles in flight: enqueue a complete encode (all kernels + the copy of the result record) and
+        return at once; `finish_whole` later waits for THIS encode only (mij_encode_result waits on a per-encode event)."""
+        self.enc.transform(self.d_img.data_ptr(), self.pitch, self.fmt, 0, stream)
+        self.enc.entropy(stream)
+
+    def finish_whole(self):
+        r = self.enc.result()
+        self.last_result = r
+        return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device)
+
     def whole_file(self):
         r = self.last_result
         return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device)

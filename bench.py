@@ -275,7 +275,6 @@ def _psnr_check(jpeg, W, H, fmt, d_img):
     Image.MAX_IMAGE_PIXELS = None
     t0 = time.perf_counter()
     dec = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB"))
-    from oracle import oracle as O
     se, band = 0.0, 2000
     for y in range(0, H, band):
         n = min(band, H - y)
@@ -283,8 +282,13 @@ def _psnr_check(jpeg, W, H, fmt, d_img):
             src = d_img[y:y + n].cpu().numpy()
             if fmt == "bgr":
                 src = src[..., ::-1]
-        else:
-            src = O.synth_rgb(W, H, y, n)
+        else:   # N > 1: rank 0 holds only its strip; regenerate the band with the library's device generator (not the oracle)
+            import torch
+            import nvjpeg_imagecompressor_amd as mij
+            t = torch.empty((n, W, 3), dtype=torch.uint8, device="cuda")
+            mij.synth_image_device(t.data_ptr(), W, y, n, W * 3, bgr=False, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            src = t.cpu().numpy()
         diff = dec[y:y + n].astype(np.int32) - src.astype(np.int32)
         se += float((diff * diff).sum())
     mse = se / (3.0 * W * H)

@@ -1,4 +1,4 @@
-"""Randomised GPU-vs-oracle sweep (not part of the test suite): random sizes, samplings, qualities, restart intervals,
+"""Randomised GPU-vs-oracle sweep (a checker script, not collected by pytest; lives under tests/ because it uses the oracle): random sizes, samplings, qualities, restart intervals,
 image statistics, baseline / fixed / progressive, encode bytes and decode pixels. Prints one line per failure."""
 import io
 import os

@@ -9,8 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from PIL import Image, ImageFile
 
+import torch
+
 import nvjpeg_imagecompressor_amd as mij
-from oracle import oracle as O
 
 ImageFile.MAXBLOCK = 1 << 28
 Image.MAX_IMAGE_PIXELS = None
@@ -18,7 +19,11 @@ Image.MAX_IMAGE_PIXELS = None
 
 def main():
     W, H = 8320, int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-    img = O.synth_rgb(W, 40000, y0=0, rows=H)
+    d = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    mij.synth_image_device(d.data_ptr(), W, 0, H, W * 3, bgr=False)     # the library's device generator, RGB
+    torch.cuda.synchronize()
+    img = d.cpu().numpy()
+    del d
     out = {}
     with mij.Encoder(W, H, 95, True, 1) as enc:
         own = enc.encode_host(img, "rgb")

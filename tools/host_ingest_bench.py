@@ -9,8 +9,9 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+import torch
+
 import nvjpeg_imagecompressor_amd as mij
-from oracle import oracle as O
 
 W, H = 8320, 40000
 
@@ -26,8 +27,12 @@ def timed(enc, img, reps=3):
 
 def main():
     pinned = mij.pinned_empty((H, W, 3))
-    for y in range(0, H, 4000):
-        pinned[y:y + 4000] = O.synth_rgb(W, H, y0=y, rows=4000)[..., ::-1]
+    d = torch.empty((4000, W, 3), dtype=torch.uint8, device="cuda:0")
+    for y in range(0, H, 4000):     # the library's device generator (SURVEY 8d synthetic image), BGR
+        mij.synth_image_device(d.data_ptr(), W, y, 4000, W * 3, bgr=True)
+        torch.cuda.synchronize()
+        pinned[y:y + 4000] = d.cpu().numpy()
+    del d
     pageable = np.array(pinned)
     enc = mij.Encoder(W, H, 95, True, 1)
     enc.encode_host(pinned, "bgr", as_view=True)      # warm-up: allocations, first-touch

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <utility>
 
 namespace mij {

@@ -156,3 +156,31 @@ def test_secondary_compression_end_to_end(mij, oracle):
     none, state = r.secondaryDecode(j1, j2[:100])
     assert none is None and state == 0
     r.deleteCompressEnv(); r.deleteDecodeEnv()
+
+
+@pytest.mark.parametrize("env", [{"MIJ_DECODE_LANES": "1"}, {"MIJ_PAR_MAX_PASSES": "1"}], ids=["lane_per_interval", "fallback_after_one_pass"])
+def test_alternative_baseline_decode_routes(env, tmp_path):
+    """The lane-per-interval kernel (k_huff_decode) stays covered: directly (A/B switch) and as the fallback the
+    subsequence-parallel decoder takes when its states do not settle (forced here by allowing a single pass). The switches
+    are read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import io, sys, numpy as np
+from PIL import Image
+sys.path.insert(0, %r)
+import nvjpeg_imagecompressor_amd as mij
+rng = np.random.default_rng(3)
+img = rng.integers(0, 256, (700, 900, 3), dtype=np.uint8)
+with mij.Decoder() as dec:
+    for kw in (dict(quality=92, subsampling=1), dict(quality=60, subsampling=2, restart_marker_blocks=9)):
+        b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", **kw); j = b.getvalue()
+        assert np.array_equal(dec.decode_host(j, "rgb"), np.asarray(Image.open(io.BytesIO(j)).convert("RGB")))
+    with mij.Encoder(900, 700, 90, True, 1) as enc:
+        j = enc.encode_host(img, "rgb")
+    assert np.array_equal(dec.decode_host(j, "rgb"), np.asarray(Image.open(io.BytesIO(j)).convert("RGB")))
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -184,3 +184,35 @@ print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_corrupt_files_are_survivable(mij, oracle):
+    """Damaged input must come back as an error or as (wrong) pixels -- never hang or fault: truncated files, a DRI that
+    promises more markers than the data holds, bytes flipped in the entropy-coded data, for both entropy routes."""
+    rng = np.random.default_rng(11)
+    img = oracle.synth_rgb(640, 480)
+    files = []
+    with mij.Encoder(640, 480, 90, True, 1, restart_interval=5) as enc:
+        files.append(enc.encode_host(img, "rgb"))
+    with mij.Encoder(640, 480, 90, True, 2, restart_interval=7, progressive=True) as enc:
+        files.append(enc.encode_host(img, "rgb"))
+    b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", quality=85); files.append(b.getvalue())      # no DRI
+    with mij.Decoder() as dec:
+        for f in files:
+            variants = [f[:len(f) // 2], f[:len(f) - 200], f[:700]]
+            dri = f.find(b"\xff\xdd")
+            if dri > 0:                      # claim a much shorter restart interval than the data was written with
+                g = bytearray(f); g[dri + 4:dri + 6] = b"\x00\x01"; variants.append(bytes(g))
+            for _ in range(6):
+                g = bytearray(f)
+                for p in rng.integers(800, len(f) - 2, 20):
+                    g[int(p)] = int(rng.integers(0, 256))
+                variants.append(bytes(g))
+            for v in variants:
+                try:
+                    out = dec.decode_host(v, "rgb")
+                    assert out.shape == (480, 640, 3)
+                except mij.MiJpegError:
+                    pass
+        # and the decoder still works afterwards
+        assert np.array_equal(dec.decode_host(files[0], "rgb"), _pil_dec(files[0]))

@@ -171,7 +171,8 @@ MIJ_API int mij_decode_info(const uint8_t *jpeg, size_t jpeg_bytes, int *width, 
 /* nvjpegJpegStreamParse + DecodeJpegHost + TransferToDevice + DecodeJpegDevice (ImageCompressorImpl.cu:362-366) with the
  * planar->interleaved step of getCVImageOnCPU (.cu:214-221) done on the device: host JPEG bytes -> device pixels.
  * output_format: MIJ_INPUT_BGRI / RGBI (interleaved, pitch >= 3*width) or MIJ_INPUT_BGR / RGB (planar, 3 planes at
- * plane_stride; the reference's NVJPEG_OUTPUT_BGR, ImageCompressorImpl.cuh:69). Returns once the entropy decoding is
+ * plane_stride; the reference's NVJPEG_OUTPUT_BGR, ImageCompressorImpl.cuh:69). `jpeg` may also point to DEVICE memory
+ * (e.g. mij_result.d_buffer + header_offset): the entropy-coded data is then decoded in place. Returns once the entropy decoding is
  * synchronised (its passes are counted from the host); the remaining kernels are asynchronous on `stream`.
  * mij_decode_sync waits and reports stream errors and the device time in ms. */
 MIJ_API int mij_decode_device(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, void *d_dst, size_t pitch,

@@ -673,7 +673,11 @@ int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *s
     e->d_sec_bytes = 2 * bytes;
   }
   uint8_t *d_dec = e->d_sec, *d_res = e->d_sec + bytes;
-  rc = mij_decode_device(dec, primary, n1, d_dec, pitch, plane_stride, fmt, nullptr);   // D = dec(J1), same layout as the input
+  mij_result r1;
+  rc = mij_encode_result(e, &r1);
+  if (rc) return rc;
+  // D = dec(J1), same layout as the input; J1 is still in the encoder's device buffer: decoded in place, no second upload
+  rc = mij_decode_device(dec, r1.d_buffer + r1.header_offset, n1, d_dec, pitch, plane_stride, fmt, nullptr);
   if (!rc) rc = mij_decode_sync(dec, nullptr);
   if (rc) return fail(e, rc, mij_decoder_last_error(dec));
   rc = mij_residual_device(e->d_src, d_dec, d_res, bytes, -1, nullptr);                 // R = clip(I - D + 128)

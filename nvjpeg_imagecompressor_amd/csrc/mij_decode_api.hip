@@ -87,7 +87,9 @@ static size_t scan_end(const uint8_t *p, size_t n, size_t i) {
 // 8-bit Huffman-coded frames: baseline / extended sequential (SOF0, SOF1) and progressive (SOF2); 1 component
 // (greyscale) or 3 components with 1x1 chroma and luma h x v, h in {1,2,4}, v in {1,2}; Huffman and quantisation table
 // ids 0..1 / 0..3. Anything else -> MIJ_ERR_BAD_STREAM with a reason.
-static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why) {
+// `total` != 0: p[0..n) is only a prefix of a file of `total` bytes (header parsing of a device-resident file); lengths that
+// refer to the entropy-coded data are then taken from `total`.
+static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why, size_t total = 0) {
   if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) { why = "not a JPEG (no SOI)"; return MIJ_ERR_BAD_STREAM; }
   size_t i = 2;
   while (i + 4 <= n) {
@@ -202,7 +204,7 @@ static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why) {
       si.off = i + 2 + len;
       // A sequential scan that carries every component is the only scan of its frame: its data runs to the end of the
       // file and need not be walked on the CPU (204 MB at the full size); anything else may be followed by more scans.
-      si.len = (!o.progressive && ns == o.ncomp) ? n - si.off : scan_end(p, n, si.off) - si.off;
+      si.len = (!o.progressive && ns == o.ncomp) ? (total ? total : n) - si.off : scan_end(p, n, si.off) - si.off;
       for (int c = 0; c < 3; c++) { o.t.td[c] = c < ns ? sd.td[c] / 2 : 0; o.t.ta[c] = c < ns ? sd.ta[c] / 2 : 0; }
       si.tab = o.t;
       if (o.scans.empty()) o.scan_off = si.off;
@@ -295,12 +297,34 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   if (!d || !jpeg || !d_dst) return dfail(d, MIJ_ERR_INVALID_ARG, "null argument");
   const bool interleaved = output_format == MIJ_INPUT_BGRI || output_format == MIJ_INPUT_RGBI;
   if (!interleaved && output_format != MIJ_INPUT_BGR && output_format != MIJ_INPUT_RGB) return dfail(d, MIJ_ERR_INVALID_ARG, "unknown output format");
-  Parsed ps; std::string why;
-  int rc = parse_jpeg(jpeg, jpeg_bytes, ps, why);
-  if (rc) return dfail(d, rc, why.c_str());
-  if (pitch < (size_t)ps.W * (interleaved ? 3 : 1)) return dfail(d, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
   DHIP(d, hipSetDevice(d->device));
   hipStream_t s = (hipStream_t)stream;
+  // The file may already sit in device memory (e.g. straight out of this library's encoder, as in the difference-map
+  // scheme): then only its header comes to the host for parsing and the kernels read the entropy-coded data in place.
+  const uint8_t *d_file = nullptr;
+  std::vector<uint8_t> hcopy;
+  {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, jpeg) == hipSuccess && at.type == hipMemoryTypeDevice) {
+      d_file = jpeg;
+      hcopy.resize(std::min<size_t>(jpeg_bytes, 1 << 16));
+      DHIP(d, hipMemcpy(hcopy.data(), d_file, hcopy.size(), hipMemcpyDeviceToHost));
+      jpeg = hcopy.data();
+    } else (void)hipGetLastError();
+  }
+  Parsed ps; std::string why;
+  int rc = parse_jpeg(jpeg, d_file ? hcopy.size() : jpeg_bytes, ps, why, d_file ? jpeg_bytes : 0);
+  if (d_file && (rc || !ps.fast)) {
+    // header longer than the prefix, or a multi-scan file whose scans must be located: bring the whole file over
+    hcopy.resize(jpeg_bytes);
+    DHIP(d, hipMemcpy(hcopy.data(), d_file, jpeg_bytes, hipMemcpyDeviceToHost));
+    jpeg = hcopy.data();
+    d_file = nullptr;
+    ps = Parsed(); why.clear();
+    rc = parse_jpeg(jpeg, jpeg_bytes, ps, why, 0);
+  }
+  if (rc) return dfail(d, rc, why.c_str());
+  if (pitch < (size_t)ps.W * (interleaved ? 3 : 1)) return dfail(d, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
   d->last_stream = s;
 
   Geom g{};
@@ -335,24 +359,26 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   }
   DHIP(d, hipEventRecord(d->ev0, s));
   // nvjpegDecodeJpegTransferToDevice (reference .cu:365): entropy-coded data + tables
-  DHIP(d, hipMemcpyAsync(d->d_scan, jpeg + data_off, scan_len, hipMemcpyHostToDevice, s));
+  const uint8_t *scan_dev = d->d_scan;
+  if (d_file) scan_dev = d_file + data_off;       // device-resident file: decode in place
+  else DHIP(d, hipMemcpyAsync(d->d_scan, jpeg + data_off, scan_len, hipMemcpyHostToDevice, s));
   DHIP(d, hipMemsetAsync(d->d_flags, 0, 2 * sizeof(uint32_t), s));
   const DecTables *d_final = d->d_tab;
   if (ps.fast) {
     DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
     DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
-    DHIP(d, launch_find_restarts(d->d_scan, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
+    DHIP(d, launch_find_restarts(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
     static const bool lanes_only = getenv("MIJ_DECODE_LANES") != nullptr;   // A/B switch: one lane per restart interval (k_huff_decode)
     if (lanes_only) {
-      DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+      DHIP(d, launch_huff_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
     } else {
       // subsequence-parallel decode (k_decode_par.inc); its synchronisation passes are checked from the host, so this
       // call waits for them (the IDCT / colour kernels that follow are still asynchronous)
       if ((rc = ensure(d, d->d_par_ws, d->par_ws_cap, par_workspace_bytes(scan_len, max_seg)))) return rc;
-      DHIP(d, launch_par_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_par_ws, d->d_flags + 2, d->d_flags + 1,
+      DHIP(d, launch_par_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_par_ws, d->d_flags + 2, d->d_flags + 1,
                                 &d->sync_passes, s));
       if (d->sync_passes < 0)   // the states did not settle within 64 passes (adversarial data): exact lane-per-interval decode
-        DHIP(d, launch_huff_decode(g, d->d_scan, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+        DHIP(d, launch_huff_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
     }
   } else {
     // generic route (k_decode_scans.inc): scans in file order into a zeroed coefficient buffer

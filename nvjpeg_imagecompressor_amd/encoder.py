@@ -183,6 +183,12 @@ class Decoder:
         self._check(self._L.mij_decode_device(self._h, buf.ctypes.data, len(jpeg), C.c_void_p(d_ptr), pitch, plane_stride,
                                               _FMT[fmt], C.c_void_p(stream)), "mij_decode_device")
 
+    def decode_device_ptr(self, d_jpeg, nbytes, d_ptr, pitch, fmt="bgr", plane_stride=0, stream=0):
+        """Like decode_device for a file that already sits in device memory (e.g. Encoder.result()): only the header is
+        copied to the host for parsing, the entropy-coded data is decoded in place."""
+        self._check(self._L.mij_decode_device(self._h, C.c_void_p(d_jpeg), nbytes, C.c_void_p(d_ptr), pitch, plane_stride,
+                                              _FMT[fmt], C.c_void_p(stream)), "mij_decode_device")
+
     def sync(self):
         ms = C.c_float()
         self._check(self._L.mij_decode_sync(self._h, C.byref(ms)), "mij_decode_sync")

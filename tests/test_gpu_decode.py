@@ -216,3 +216,20 @@ def test_corrupt_files_are_survivable(mij, oracle):
                     pass
         # and the decoder still works afterwards
         assert np.array_equal(dec.decode_host(files[0], "rgb"), _pil_dec(files[0]))
+
+
+def test_decode_file_resident_in_device_memory(mij, oracle):
+    """A file that already sits in HBM (straight out of the encoder) is decoded in place: same pixels, baseline and
+    progressive (the latter goes through the host because its scans have to be located)."""
+    import torch
+    W, H = 1040, 536
+    img = oracle.synth_rgb(W, H)
+    for prog in (False, True):
+        with mij.Encoder(W, H, 92, True, 2, progressive=prog) as enc, mij.Decoder() as dec:
+            jpg = enc.encode_host(img, "rgb")
+            r = enc.result()
+            out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+            dec.decode_device_ptr(r["d_buffer"] + r["header_offset"], r["file_bytes"], out.data_ptr(), W * 3, "rgb")
+            dec.sync()
+            assert r["file_bytes"] == len(jpg)
+            assert np.array_equal(out.cpu().numpy(), _pil_dec(jpg))

@@ -7,6 +7,13 @@
 //   K4 k_encode        Huffman coding + bit packing, one restart interval per wavefront                (A5+A7)
 //   K5 k_scan          exclusive scan of interval sizes                                                (A7)
 //   K6 k_compact       FF00 byte stuffing + compaction + RSTn / EOI markers                            (A7)
+//   KP k_prog_encode   progressive (SOF2) scans: libjpeg's script, gather / emit per scan, lane per restart interval   (k_encode_prog.inc)
+// and, for the decode half (nvjpegDecodeJpeg*, ImageCompressorImpl.cu:361-366; getCVImageOnCPU, .cu:184-232):
+//   D1 k_rst_count/write   restart-marker positions                                                    (k_decode.inc)
+//   D2p k_par_decode<0..3> subsequence-parallel, self-synchronising Huffman decode of baseline scans   (k_decode_par.inc)
+//   D2 k_huff_decode       lane per restart interval (fallback)                                        (k_decode.inc)
+//   D2s k_scan_decode      progressive / multi-scan / greyscale scans                                  (k_decode_scans.inc)
+//   D3 k_idct, D4 k_upsample_color[8], k_residual   IDCT, upsampling + colour, difference map          (k_decode.inc)
 // No MFMA anywhere: this path is integer/byte work bounded by HBM and by VALU issue, not a contraction.
 // Wavefront = 64 lanes throughout.
 #include "mij_internal.h"

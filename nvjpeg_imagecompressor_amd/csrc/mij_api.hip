@@ -452,8 +452,17 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
     off += h.size();
     data_off[i] = off;
     const size_t sb = (size_t)e->h_prog_res[i].scan_bytes;
-    if (sb < 2 || off + sb + 2 > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "output buffer too small for the progressive file");
+    if (sb < 2) return fail(e, MIJ_ERR_OVERFLOW, "progressive scan produced no data");
     off += sb - 2;                          // K6 ends every interval with RSTn; the last one of a scan has none: overwritten
+  }
+  if (off + 4 > e->capacity) {
+    // larger than the preallocated buffer (noise at q100 with a restart marker after every block in every scan): all
+    // sizes are known before anything is placed, so simply make room
+    const size_t need = off + 65536;
+    uint8_t *nb = nullptr;
+    if (hipMalloc(&nb, HDR_AREA + need) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
+    (void)hipFree(e->d_out);
+    e->d_out = nb; e->capacity = need;
   }
   uint8_t *const file = e->d_out + HDR_AREA;
   Geom g2 = g; g2.last_strip = 0; g2.mcu_first = 0;       // K6: RSTn numbering restarts in every scan, never an EOI

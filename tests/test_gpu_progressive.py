@@ -99,3 +99,16 @@ def test_progressive_eob_run_cap_and_correction_flush(mij, oracle):
     for q in (100, 98):
         with mij.Encoder(512, 512, q, True, 0, progressive=True) as enc:
             assert enc.encode_host(noise, "rgb") == oracle.encode_progressive(noise, q, 0, enc.geometry["restart_interval"])
+
+
+def test_progressive_output_larger_than_the_preallocated_buffer(mij, oracle):
+    """Noise at q100 with a restart marker after every block of every scan: the file outgrows 2 bytes per coefficient."""
+    rng = np.random.default_rng(9)
+    W, H = 1280, 400
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    with mij.Encoder(W, H, 100, True, 0, restart_interval=1, progressive=True) as enc:
+        got = enc.encode_host(img, "rgb")
+    assert got == oracle.encode_progressive(img, 100, 0, 1)
+    assert len(got) > (W // 8) * (H // 8) * 3 * 64 + 65536      # really beyond the initial capacity (2 B per coefficient)
+    dec = np.asarray(Image.open(io.BytesIO(got)).convert("RGB"))
+    assert dec.shape == img.shape

@@ -37,18 +37,32 @@ for it in range(N):
             img[rng.integers(0, H), rng.integers(0, W)] = rng.integers(0, 256, 3)
     mode = int(rng.integers(0, 3))   # 0 optimised, 1 fixed tables, 2 progressive
     ri = int(rng.choice([-1, 1, 2, 5, 17, 64]))
+    fmt = str(rng.choice(["rgb", "bgr", "rgb_planar", "bgr_planar"]))      # input layout: same file whatever the layout
+    src = img if fmt.startswith("rgb") else img[..., ::-1]
+    src = np.ascontiguousarray(src.transpose(2, 0, 1)) if fmt.endswith("planar") else np.ascontiguousarray(src)
     try:
         with mij.Encoder(W, H, q, mode != 1, css, restart_interval=ri, progressive=(mode == 2)) as enc:
             r = enc.geometry["restart_interval"]
-            got = enc.encode_host(img, "rgb")
+            got = enc.encode_host(src, fmt)
         want = O.encode_progressive(img, q, css, r) if mode == 2 else O.encode(img, q, css, mode != 1, r)
         ok = got == want
         if ok:
             pix = dec.decode_host(got, "rgb")
             ok = np.array_equal(pix, np.asarray(Image.open(io.BytesIO(got)).convert("RGB")))
+        if ok and it % 3 == 0 and css < 3:
+            # a third-party file of the same picture (libjpeg-turbo via Pillow): baseline / progressive, with / without DRI
+            from PIL import ImageFile
+            ImageFile.MAXBLOCK = 1 << 27
+            kw = dict(quality=q, subsampling=css, progressive=bool(rng.integers(0, 2)), optimize=bool(rng.integers(0, 2)))
+            if rng.integers(0, 2):
+                kw["restart_marker_blocks"] = int(rng.integers(1, 50))
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, "JPEG", **kw)
+            tp = b.getvalue()
+            ok = np.array_equal(dec.decode_host(tp, "bgr")[..., ::-1], np.asarray(Image.open(io.BytesIO(tp)).convert("RGB")))
         if not ok:
             bad += 1
-            print("FAIL", dict(W=W, H=H, css=css, q=q, kind=kind, mode=mode, ri=ri), flush=True)
+            print("FAIL", dict(W=W, H=H, css=css, q=q, kind=kind, mode=mode, ri=ri, fmt=fmt), flush=True)
     except Exception as e:
         bad += 1
         print("EXC", dict(W=W, H=H, css=css, q=q, kind=kind, mode=mode, ri=ri), repr(e)[:200], flush=True)

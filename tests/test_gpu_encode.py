@@ -139,3 +139,17 @@ def test_gpu_output_equals_committed_libjpeg_turbo_files(mij, oracle, case):
     with mij.Encoder(w, h, case["quality"], case["optimize"], case["css"], restart_interval=case["restart"],
                      progressive=bool(case.get("progressive"))) as enc:
         assert enc.encode_host(img, "rgb") == want
+
+
+def test_output_larger_than_the_preallocated_buffer(mij, oracle):
+    """Black/white noise at q100 with a restart marker after every MCU: more than one byte per coefficient, the initial
+    capacity. The encoder grows its output buffer and redoes header + compaction (mij_encode_result)."""
+    rng = np.random.default_rng(9)
+    W, H = 1280, 400
+    img = rng.integers(0, 2, (H, W, 3), dtype=np.uint8) * 255
+    for optimize in (True, False):
+        with mij.Encoder(W, H, 100, optimize, 0, restart_interval=1) as enc:
+            got = enc.encode_host(img, "rgb")
+            assert len(got) > (W // 8) * (H // 8) * 3 * 64 + 65536
+            assert got == oracle.encode(img, 100, 0, optimize, 1)
+            assert enc.encode_host(img, "rgb") == got          # and again, now that the buffer is large enough

@@ -22,7 +22,7 @@ for it in range(N):
     W, H = int(rng.integers(1, 700 * SCALE)), int(rng.integers(1, 500 * SCALE))
     css = int(rng.integers(0, 6))
     q = int(rng.choice([1, 3, 10, 25, 50, 75, 90, 95, 100]))
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     if kind == 0:
         img = O.synth_rgb(W, H)
     elif kind == 1:
@@ -30,6 +30,8 @@ for it in range(N):
     elif kind == 2:
         img = np.full((H, W, 3), rng.integers(0, 256, 3), np.uint8)
         img[rng.integers(0, H):, rng.integers(0, W):] = rng.integers(0, 256, 3)
+    elif kind == 4:   # black / white noise: the largest blocks there are (entropy coder's roomy path, output-buffer growth)
+        img = rng.integers(0, 2, (H, W, 3), dtype=np.uint8) * 255
     else:   # smooth gradient + sparse impulses: long zero runs with isolated coefficients
         yy, xx = np.mgrid[0:H, 0:W]
         img = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy) % 256)], -1).astype(np.uint8)

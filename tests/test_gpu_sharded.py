@@ -56,3 +56,15 @@ def test_hip_strips_equal_one_shot(oracle, tmp_path, world, css, optimize):
     want = oracle.encode(oracle.synth_rgb(W, H), 95, css, optimize, ri)
     got = out.read_bytes()
     assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want)
+
+
+def test_hip_strips_five_ranks_uneven(oracle, tmp_path):
+    """Five ranks (the most the test box lets share its GPU next to the test process), strips of unequal height, bottom
+    edge inside the last strip, 4:2:0 so that an MCU row is 16 pixels."""
+    W, H, css, world = 4160, 2504, 2, 5
+    out = tmp_path / "sharded5.jpg"
+    mp.spawn(_worker, args=(world, _free_port(), W, H, css, True, str(out)), nprocs=world, join=True)
+    ri = int(open(str(out) + ".ri").read())
+    want = oracle.encode(oracle.synth_rgb(W, H), 95, css, True, ri)
+    got = out.read_bytes()
+    assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want)

@@ -89,16 +89,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switches (tests only): all ranks on GPU 0 with gloo carrying the collectives, because RCCL refuses two ranks
+    # on one device. The measured runs use one GPU per rank over RCCL/xGMI.
+    one_device = os.environ.get("MIJ_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     optimize = not args.no_optimize
     W, H = args.width, args.height
 
     # ---- strip partition (pure arithmetic, no communication) + this rank's pixels --------------------------------
-    enc = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, local_rank, args.fmt,
+    enc = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
                                          progressive=args.progressive)
     geo = enc.geometry
     y0, rows = geo["strip_y0"], geo["strip_rows"]
@@ -118,7 +125,7 @@ def main():
     pipelined = world == 1 and not args.progressive
     strips = [strip]
     if pipelined:
-        enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, local_rank, args.fmt)
+        enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt)
         enc2.enable_timing(True)
         strips.append(sharded.HipStripEncoder(torch, enc2, d_img, args.fmt))
     state = {"i": 0, "pending": None}

@@ -349,6 +349,7 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   a.coef = e->d_coef + (size_t)skip * g.bpm * 64;
   a.dc = e->d_dc + (size_t)skip * g.bpm;
   memcpy(a.recip, e->hq.recip, sizeof(a.recip));
+  a.recip_dev = &e->d_qt->recip[0][0];
   a.hist = (e->p.optimized_huffman && !e->p.progressive) ? e->d_hist : nullptr;   // progressive gathers per scan instead
   if (sub.mcu_count > 0) HIPCHK(e, launch_transform(sub, a, interleaved ? 1 : 0, s));
   if (last) {

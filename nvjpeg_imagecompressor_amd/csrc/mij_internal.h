@@ -71,6 +71,7 @@ struct TransformArgs {
   float fA[3], fC[3];     // colour matrix rows (Y, Cb, Cr) for the first / third stored channel, times 2^-16; G is fixed
   int16_t *coef;
   float recip[2][64];     // quantiser reciprocals r' (see quant_magic); by value so they are always scalar loads
+  const float *recip_dev; // the same 128 values in device memory (experiment MIJ_K1_RECIP_PTR: scalar loads per use instead)
   uint32_t *hist;         // non-null: optimised Huffman, take AC statistics (rows 1 and 3 of the 4 x 257 table)
   int16_t *dc;            // compact DC array [strip blocks] (written when hist != null)
 };

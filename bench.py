@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-optimize", action="store_true")
     ap.add_argument("--progressive", action="store_true", help="SOF2 output (the reference's nvJPEG setting); 1 GPU only, not the headline config")
     ap.add_argument("--fmt", default="bgr", choices=["bgr", "rgb"])
+    ap.add_argument("--two-streams", action="store_true", help="experiment: the two images in flight run on two HIP streams, so one "
+                    "image's small serial kernels overlap the other's wide ones (per-kernel event times then include the sharing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1000, help="rows per CPU-baseline strip (one strip per core)")
@@ -129,6 +131,10 @@ def main():
         enc2.enable_timing(True)
         strips.append(sharded.HipStripEncoder(torch, enc2, d_img, args.fmt))
     state = {"i": 0, "pending": None}
+    streams = [torch.cuda.current_stream().cuda_stream] * 2
+    if pipelined and args.two_streams:
+        second = torch.cuda.Stream()
+        streams = [streams[0], second.cuda_stream]
 
     def collect(record):
         s_prev = state["pending"]
@@ -149,8 +155,8 @@ def main():
                     stage_acc[k] = stage_acc.get(k, 0.0) + v
             return out
         cur = strips[state["i"] & 1]
+        cur.issue_whole(streams[state["i"] & 1])
         state["i"] += 1
-        cur.issue_whole(torch.cuda.current_stream().cuda_stream)
         out = collect(record)          # the previous image, while this one runs
         state["pending"] = cur
         return out
@@ -217,7 +223,7 @@ def main():
                                    "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
-                       "images_in_flight": 2 if pipelined else 1},
+                       "images_in_flight": 2 if pipelined else 1, "streams": 2 if (pipelined and args.two_streams) else 1},
             "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
             "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None, "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }

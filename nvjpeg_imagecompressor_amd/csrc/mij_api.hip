@@ -100,8 +100,7 @@ static void make_quant(int quality, Quant &q) {
       v = std::min(255L, std::max(1L, v));
       q.q[t][i] = (uint16_t)v;
       const float d = (float)(8 * v);
-      { float r = 1.0f / d; q.recip[t][i] = r * (1.0f + 0x1p-17f); }   // see quant_magic() in k_common.inc
-      q.bias[t][i] = 0.0f;
+      q.recip[t][i] = (1.0f / d) * (1.0f + 0x1p-17f);   // see quant_magic() in k_common.inc
     }
 }
 
@@ -348,7 +347,6 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   sub.mcu_count = std::min((long long)rows * g.mcux, g.mcu_count - skip);
   a.coef = e->d_coef + (size_t)skip * g.bpm * 64;
   a.dc = e->d_dc + (size_t)skip * g.bpm;
-  memcpy(a.recip, e->hq.recip, sizeof(a.recip));
   a.recip_dev = &e->d_qt->recip[0][0];
   a.hist = (e->p.optimized_huffman && !e->p.progressive) ? e->d_hist : nullptr;   // progressive gathers per scan instead
   if (sub.mcu_count > 0) HIPCHK(e, launch_transform(sub, a, interleaved ? 1 : 0, s));

@@ -26,8 +26,7 @@ constexpr int MAX_BLOCK_WORDS = 53;     // ceil((16+11 + 63*(16+10)) / 32) + 1 :
 constexpr int MAX_BLOCK_BYTES = 212;
 
 struct Quant {            // natural (row-major) coefficient order; [0] luma [1] chroma
-  float recip[2][64];     // 1 / (8 q)
-  float bias[2][64];      // (4 q + 0.5) / (8 q)
+  float recip[2][64];     // quantiser reciprocals r' (see quant_magic in k_common.inc)
   uint16_t q[2][64];
 };
 
@@ -70,8 +69,9 @@ struct TransformArgs {
   const uint8_t *src; size_t pitch, plane_stride;
   float fA[3], fC[3];     // colour matrix rows (Y, Cb, Cr) for the first / third stored channel, times 2^-16; G is fixed
   int16_t *coef;
-  float recip[2][64];     // quantiser reciprocals r' (see quant_magic); by value so they are always scalar loads
-  const float *recip_dev; // the same 128 values in device memory (experiment MIJ_K1_RECIP_PTR: scalar loads per use instead)
+  const float *recip_dev; // Quant::recip in device memory, read with scalar loads at the point of use (by value in the kernel
+                          // arguments the 128 values were parked in SGPRs for the whole kernel and spilled through v_writelane;
+                          // regrouped for one 64-byte load per column pair they were 1.3 % slower than these 8-byte loads)
   uint32_t *hist;         // non-null: optimised Huffman, take AC statistics (rows 1 and 3 of the 4 x 257 table)
   int16_t *dc;            // compact DC array [strip blocks] (written when hist != null)
 };

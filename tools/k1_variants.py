@@ -14,10 +14,11 @@ CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default" is what ships
     "default": {},
+    "k4_nofallback": {"MIJ_K4_NOFALLBACK": 1},
     "direct_stores": {"MIJ_K1_STAGED": 0},
     "copies2": {"MIJ_HIST_COPIES": 2},
     "no_atomics": {"MIJ_K1_STATMODE": 1},
-    "predicated_atomics": {"MIJ_K1_STATMODE": 3},
+    "nz_from_size": {"MIJ_K1_NZ_FROM_SIZE": 1},
 }
 
 
@@ -45,14 +46,15 @@ def build():
 
 
 def run(extra):
-    for name in VARIANTS:
+    # `prev`: a library built by hand from an earlier commit, for A/B runs on the same box
+    for name in list(VARIANTS) + [d for d in ("prev",) if os.path.exists(os.path.join(OUT, d, "libmijpeg.so"))]:
         lib = os.path.join(OUT, name, "libmijpeg.so")
         env = dict(os.environ, MIJ_LIB_PATH=lib)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-psnr"] + extra,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-psnr"] + extra,
                            capture_output=True, text=True, env=env)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            print("%-20s transform %.4f ms  total %.4f  crc %s" % (name, d["stage_ms"]["transform"], d["ms_per_step"], d["jpeg_crc32"]), flush=True)
+            print("%-20s transform %.4f ms  entropy %.4f  total %.4f  crc %s" % (name, d["stage_ms"]["transform"], d["stage_ms"]["entropy"], d["ms_per_step"], d["jpeg_crc32"]), flush=True)
         except Exception:
             print(name, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
 

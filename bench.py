@@ -123,7 +123,7 @@ def main():
 
     # One GPU: two encoder handles alternate on the stream, so image i+1's kernels are already queued while the host
     # collects image i's result (size, stage times). Every step still produces a complete file inside the timed region;
-    # what disappears is the GPU idling during the host's round trip (~35 us of a 1.7 ms step).
+    # what disappears is the GPU idling during the host's round trip (~35 us of a 1.6 ms step).
     pipelined = world == 1 and not args.progressive
     strips = [strip]
     if pipelined:

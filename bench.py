@@ -121,10 +121,12 @@ def main():
     copy_gbs = hbm_copy_ceiling(torch, dev) if rank == 0 else None
     cache, stage_acc = {}, {}
 
-    # One GPU: two encoder handles alternate on the stream, so image i+1's kernels are already queued while the host
-    # collects image i's result (size, stage times). Every step still produces a complete file inside the timed region;
-    # what disappears is the GPU idling during the host's round trip (~35 us of a 1.6 ms step).
-    pipelined = world == 1 and not args.progressive
+    # Two encoder handles alternate, so that an image's kernels are queued while the host collects the previous image's
+    # result (size, stage times). Every step still produces a complete file inside the timed region.
+    #  * One GPU: what disappears is the GPU idling during the host's round trip (~35 us of a 1.6 ms step).
+    #  * N GPUs (sharded.StripPipeline): the gather of image i-1 to rank 0 and the host round trips for its strip sizes
+    #    overlap image i's kernels. MIJ_BENCH_NO_PIPELINE=1 falls back to one image at a time (sharded.encode_step).
+    pipelined = not args.progressive and not (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1")
     strips = [strip]
     if pipelined:
         enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt)
@@ -132,27 +134,42 @@ def main():
         strips.append(sharded.HipStripEncoder(torch, enc2, d_img, args.fmt))
     state = {"i": 0, "pending": None}
     streams = [torch.cuda.current_stream().cuda_stream] * 2
-    if pipelined and args.two_streams:
+    if pipelined and world == 1 and args.two_streams:
         second = torch.cuda.Stream()
         streams = [streams[0], second.cuda_stream]
+    pipe = sharded.StripPipeline(torch, dist, strips, optimize) if (pipelined and world > 1) else None
+
+    def record_times(e):
+        for k, v in e.stage_times().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
 
     def collect(record):
+        if pipe is not None:                      # the last image of a multi-rank run
+            prev = pipe.pending
+            out = pipe.flush()
+            if record and prev is not None:
+                record_times(prev[0].enc)
+            return out
         s_prev = state["pending"]
         state["pending"] = None
         if s_prev is None:
             return None
         out = s_prev.finish_whole()
         if record:
-            for k, v in s_prev.enc.stage_times().items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
+            record_times(s_prev.enc)
         return out
 
     def step(record):
         if not pipelined:
             out = sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
             if record:
-                for k, v in enc.stage_times().items():
-                    stage_acc[k] = stage_acc.get(k, 0.0) + v
+                record_times(enc)
+            return out
+        if pipe is not None:
+            prev = pipe.pending
+            out = pipe.step()                     # issues this image, then completes the previous one
+            if record and prev is not None:
+                record_times(prev[0].enc)
             return out
         cur = strips[state["i"] & 1]
         cur.issue_whole(streams[state["i"] & 1])
@@ -223,7 +240,7 @@ def main():
                                    "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
-                       "images_in_flight": 2 if pipelined else 1, "streams": 2 if (pipelined and args.two_streams) else 1},
+                       "images_in_flight": 2 if pipelined else 1, "streams": 2 if (pipelined and world == 1 and args.two_streams) else 1},
             "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
             "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None, "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }

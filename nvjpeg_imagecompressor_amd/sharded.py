@@ -60,6 +60,17 @@ class HipStripEncoder:
         return (self._view(r["d_buffer"] + r["header_offset"], r["header_bytes"], dev),
                 self._view(r["d_buffer"] + r["scan_offset"], r["scan_bytes"], dev))
 
+    def issue_entropy(self, stream=0):
+        """Enqueue the entropy stage and return at once (pipelined multi-rank step); `collect_strip` waits for it."""
+        self.enc.entropy(stream)
+
+    def collect_strip(self):
+        r = self.enc.result()    # waits for this strip only (per-encode event)
+        self.last_result = r
+        dev = self.d_img.device
+        return (self._view(r["d_buffer"] + r["header_offset"], r["header_bytes"], dev),
+                self._view(r["d_buffer"] + r["scan_offset"], r["scan_bytes"], dev))
+
     def encode_whole(self, stream=0):
         """Single-rank shortcut: entropy-code and return the complete file (header and scan sit back to back in the
         encoder's buffer), without building the separate header / scan views nobody would read."""
@@ -122,13 +133,73 @@ def encode_step(torch, dist, strip_encoder, optimize, out_cache, stream=0):
         buf[:header.numel()].copy_(header)
         buf[header.numel():n].copy_(scan)
         return buf[:n]
+    return _gather_to_rank0(torch, dist, header, scan, out_cache)
+
+
+class StripPipeline:
+    """Multi-rank encode with TWO images in flight per rank, so that the gather of image i-1 to rank 0 (the longest leg:
+    (N-1)/N of the file crosses rank 0's xGMI links) and the host round trips for its sizes run while image i's kernels
+    do. Every rank executes the same sequence of collectives, in the same order:
+
+        step i:   transform(i) -> all_reduce(statistics i) -> entropy(i)           [enqueued, no host wait]
+                  sizes(i-1): all_gather -> host;  gather(i-1): point-to-point      [on a side stream]
+
+    Two strip encoders (handles) alternate; a handle is reused only after the sends that read its bitstream are complete
+    (the compute stream waits for the side stream at the start of a step). `step` returns, on rank 0, the complete file
+    of the PREVIOUS image (None for the first call); `flush` returns the last one.
+    """
+
+    def __init__(self, torch, dist, strips, optimize):
+        assert len(strips) == 2
+        self.torch, self.dist, self.strips, self.optimize = torch, dist, strips, optimize
+        self.caches = [{}, {}]
+        self.i, self.pending = 0, None
+        d_img = getattr(strips[0], "d_img", None)
+        self.side = torch.cuda.Stream() if (d_img is not None and d_img.is_cuda) else None   # CPU tests: no streams
+
+    def step(self):
+        torch, dist = self.torch, self.dist
+        k = self.i & 1
+        self.i += 1
+        cur = self.strips[k]
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)     # the sends of image i-2 (same handle) are done
+        stream = torch.cuda.current_stream().cuda_stream if self.side is not None else 0
+        hist = cur.transform(stream)
+        if self.optimize:
+            dist.all_reduce(hist)
+        cur.issue_entropy(stream)
+        out = self._finish()
+        self.pending = (cur, self.caches[k])
+        return out
+
+    def flush(self):
+        out = self._finish()
+        if self.side is not None:
+            self.torch.cuda.current_stream().wait_stream(self.side)
+        return out
+
+    def _finish(self):
+        if self.pending is None:
+            return None
+        (s, cache), self.pending = self.pending, None
+        header, scan = s.collect_strip()
+        if self.side is None:
+            return _gather_to_rank0(self.torch, self.dist, header, scan, cache)
+        with self.torch.cuda.stream(self.side):
+            return _gather_to_rank0(self.torch, self.dist, header, scan, cache)
+
+
+def _gather_to_rank0(torch, dist, header, scan, cache):
+    """all_gather of the strip sizes, then the strips travel to rank 0 point-to-point (same protocol as encode_step)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
     mine = torch.tensor([scan.numel()], dtype=torch.int64, device=scan.device)
     sizes = torch.zeros(world, dtype=torch.int64, device=scan.device)
     dist.all_gather_into_tensor(sizes, mine)
     sz = [int(v) for v in sizes.cpu().tolist()]
     if rank == 0:
         total = header.numel() + sum(sz)
-        buf = _buffer(torch, out_cache, total, scan.device)
+        buf = _buffer(torch, cache, total, scan.device)
         off = header.numel()
         buf[:off].copy_(header)
         buf[off:off + sz[0]].copy_(scan)

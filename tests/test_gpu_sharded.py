@@ -70,21 +70,25 @@ def test_hip_strips_five_ranks_uneven(oracle, tmp_path):
     assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want)
 
 
-def test_bench_multi_rank_rehearsal(tmp_path):
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_bench_multi_rank_rehearsal(tmp_path, pipeline):
     """bench.py's N > 1 path end to end (launcher, strips, collectives, gather, the JSON line), rehearsed with three ranks
-    on the one GPU over gloo: the file must be the single-GPU file."""
+    on the one GPU over gloo: the file must be the single-GPU file. Both forms of the step: two images in flight per
+    rank (sharded.StripPipeline, the default) and one at a time (sharded.encode_step)."""
     import json
     import subprocess
     env = dict(os.environ, MIJ_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    if not pipeline:
+        env["MIJ_BENCH_NO_PIPELINE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", "--height", "4000"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 3 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == 1
+    assert d["n_gpus"] == 3 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == (2 if pipeline else 1)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--no-psnr", "--height", "4000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-3000:]

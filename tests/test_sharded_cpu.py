@@ -42,6 +42,44 @@ class OracleStripEncoder:
         return buf[:hdr_len], buf[hdr_len:]
 
 
+    # the pipelined step splits entropy() into "enqueue" and "collect"; on CPU the work simply happens at collect time
+    def issue_entropy(self, stream=0):
+        pass
+
+    def collect_strip(self):
+        return self.entropy()
+
+
+def _pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, out_path):
+    """StripPipeline: `nimg` different images through two alternating strip encoders; rank 0 saves every file."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from nvjpeg_imagecompressor_amd import sharded
+    geo = O.geometry(W, H, css)
+    unit = sharded.rows_per_restart_unit(geo["mcux"], ri)
+    r0, r1 = sharded.partition_mcu_rows(geo["mcuy"], world, rank, unit)
+    mcu_h = 8 * geo["vs"]
+    y0, y1 = r0 * mcu_h, min(r1 * mcu_h, H)
+    encs = [OracleStripEncoder(O, None, W, H, q, css, optimize, ri, r0, r1, geo) for _ in range(2)]
+    pipe = sharded.StripPipeline(torch, dist, encs, optimize)
+    outs = []
+    for i in range(nimg):
+        encs[i & 1].img = np.roll(O.synth_rgb(W, H), 7 * i, axis=1)[y0:y1].copy()    # image i
+        o = pipe.step()
+        outs.append(None if o is None else o.clone())     # the returned view is valid until its buffer's next image
+    o = pipe.flush()
+    outs.append(None if o is None else o.clone())
+    assert outs[0] is None
+    if rank == 0:
+        for i, o in enumerate(outs[1:]):
+            open(out_path + ".%d" % i, "wb").write(o.numpy().tobytes())
+    else:
+        assert all(o is None for o in outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, W, H, css, optimize, ri, q, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -80,6 +118,18 @@ def test_n_rank_file_equals_one_rank_file(oracle, tmp_path, world, css, optimize
     want = oracle.encode(oracle.synth_rgb(W, H), q, css, optimize, ri)
     got = out.read_bytes()
     assert got == want
+
+
+@pytest.mark.parametrize("world,optimize", [(2, True), (3, True), (2, False)])
+def test_pipelined_step_two_images_in_flight(oracle, tmp_path, world, optimize):
+    """The bench's N > 1 step keeps two images in flight per rank (StripPipeline): every image must still come out as
+    the 1-rank file, in order, and the collectives must line up across ranks (a mismatch would hang or corrupt)."""
+    W, H, q, css, ri, nimg = 208, 250, 92, 1, 13, 5
+    out = str(tmp_path / "pipe.jpg")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, nimg, out), nprocs=world, join=True)
+    for i in range(nimg):
+        want = oracle.encode(np.roll(oracle.synth_rgb(W, H), 7 * i, axis=1).copy(), q, css, optimize, ri)
+        assert open(out + ".%d" % i, "rb").read() == want, i
 
 
 def test_partition_arithmetic():

@@ -48,6 +48,15 @@
 #define I_MADI16(n)   "v_mad_i16 %" #n ", %" #n ", %16, %17\n"
 #define I_SDWA(n)     "v_add_u32_sdwa %" #n ", %" #n ", %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
 #define I_SHL64(n)    "v_lshlrev_b64 %" #n ", %16, %" #n "\n"
+#define I_PKFMA(n)    "v_pk_fma_f32 %" #n ", %" #n ", %" #n ", %" #n "\n"
+#define I_PKMULF(n)   "v_pk_mul_f32 %" #n ", %" #n ", %" #n "\n"
+#define I_PKADDF(n)   "v_pk_add_f32 %" #n ", %" #n ", %" #n "\n"
+#define I_MAXU(n)     "v_max_u32 %" #n ", %" #n ", %16\n"
+#define I_MINU(n)     "v_min_u32 %" #n ", %" #n ", %16\n"
+#define I_CVTUB(n)    "v_cvt_f32_ubyte1 %" #n ", %" #n "\n"
+#define I_ADDF(n)     "v_add_f32 %" #n ", %" #n ", %16\n"
+#define I_XOR(n)      "v_xor_b32 %" #n ", %" #n ", %16\n"
+#define I_SUB(n)      "v_sub_u32 %" #n ", %" #n ", %16\n"
 #define I_DOT4(n)     "v_dot4_i32_i8 %" #n ", %" #n ", %16, %17\n"
 #define I_DOT2(n)     "v_dot2_i32_i16 %" #n ", %" #n ", %16, %17\n"
 #define I_CVTPK(n)    "v_cvt_pk_i16_i32 %" #n ", %" #n ", %16\n"
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t b, uint32_t 
   X(k_cvtfi, I_CVTFI, 0) X(k_cvtif, I_CVTIF, 0) X(k_fma, I_FMA, 0) X(k_frexp, I_FREXP, 0) X(k_alignbit, I_ALIGNBIT, 0) X(k_perm, I_PERM, 0) \
   X(k_max, I_MAX, 0) X(k_ffbh, I_FFBH, 0) X(k_bcnt, I_BCNT, 0) X(k_bfi, I_BFI, 0) X(k_pkadd, I_PKADD, 0) X(k_pkmul, I_PKMUL, 0) X(k_pkmad, I_PKMAD, 0) \
   X(k_pkashr, I_PKASHR, 0) X(k_pkmax, I_PKMAX, 0) X(k_madi16, I_MADI16, 0) X(k_sdwa, I_SDWA, 0) X(k_shl64, I_SHL64, 1) X(k_dot4, I_DOT4, 0) X(k_dot2, I_DOT2, 0) \
-  X(k_cvtpk, I_CVTPK, 0) X(k_mov, I_MOV, 0) X(k_sad, I_SAD, 0) X(k_med3, I_MED3, 0)
+  X(k_pkfma, I_PKFMA, 1) X(k_pkmulf, I_PKMULF, 1) X(k_pkaddf, I_PKADDF, 1) X(k_maxu, I_MAXU, 0) X(k_minu, I_MINU, 0) X(k_cvtub, I_CVTUB, 0) X(k_addf, I_ADDF, 0) X(k_xor, I_XOR, 0) X(k_sub, I_SUB, 0) X(k_cvtpk, I_CVTPK, 0) X(k_mov, I_MOV, 0) X(k_sad, I_SAD, 0) X(k_med3, I_MED3, 0)
 
 LIST(KERNEL)
 

@@ -123,7 +123,7 @@ def main():
 
     # Two encoder handles alternate, so that an image's kernels are queued while the host collects the previous image's
     # result (size, stage times). Every step still produces a complete file inside the timed region.
-    #  * One GPU: what disappears is the GPU idling during the host's round trip (~35 us of a 1.6 ms step).
+    #  * One GPU: what disappears is the GPU idling during the host's round trip (~35 us of a 1.5 ms step).
     #  * N GPUs (sharded.StripPipeline): the gather of image i-1 to rank 0 and the host round trips for its strip sizes
     #    overlap image i's kernels. MIJ_BENCH_NO_PIPELINE=1 falls back to one image at a time (sharded.encode_step).
     pipelined = not args.progressive and not (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1")

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-optimize", action="store_true")
     ap.add_argument("--progressive", action="store_true", help="SOF2 output (the reference's nvJPEG setting); 1 GPU only, not the headline config")
     ap.add_argument("--fmt", default="bgr", choices=["bgr", "rgb"])
+    ap.add_argument("--restart-interval", type=int, default=-1, help="DRI in MCUs; -1 = the library's automatic choice (the headline config)")
     ap.add_argument("--two-streams", action="store_true", help="experiment: the two images in flight run on two HIP streams, so one "
                     "image's small serial kernels overlap the other's wide ones (per-kernel event times then include the sharing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,7 +109,7 @@ def main():
 
     # ---- strip partition (pure arithmetic, no communication) + this rank's pixels --------------------------------
     enc = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
-                                         progressive=args.progressive)
+                                         restart_interval=args.restart_interval, progressive=args.progressive)
     geo = enc.geometry
     y0, rows = geo["strip_y0"], geo["strip_rows"]
     d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
@@ -129,7 +130,8 @@ def main():
     pipelined = not args.progressive and not (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1")
     strips = [strip]
     if pipelined:
-        enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt)
+        enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
+                                              restart_interval=args.restart_interval)
         enc2.enable_timing(True)
         strips.append(sharded.HipStripEncoder(torch, enc2, d_img, args.fmt))
     state = {"i": 0, "pending": None}

@@ -51,7 +51,14 @@ enum { MIJ_INPUT_RGB = 3, MIJ_INPUT_BGR = 4, MIJ_INPUT_RGBI = 5, MIJ_INPUT_BGRI 
 
 typedef struct mij_encoder mij_encoder;
 
+/* ABI version of this header. mij_encoder_params starts with its own size so that a caller compiled against an older
+ * (shorter) layout is recognised instead of being read past its end: fields the caller's struct does not have are taken
+ * as 0; a size this library does not know is rejected (MIJ_ERR_INVALID_ARG). Use MIJ_ENCODER_PARAMS_INIT or set
+ * struct_size = sizeof(mij_encoder_params). */
+#define MIJ_ABI_VERSION 2
+
 typedef struct mij_encoder_params {
+  uint32_t struct_size;    /* = sizeof(mij_encoder_params) of the header the CALLER was compiled with */
   int width, height;       /* full image size; reference ctor args (ImageCompressor.h:27), default 8320 x 40000 */
   int quality;             /* 1..100, IJG scaling; nvjpegEncoderParamsSetQuality (ImageCompressorImpl.cu:30) */
   int optimized_huffman;   /* nvjpegEncoderParamsSetOptimizedHuffman (ImageCompressorImpl.cu:29) */
@@ -70,6 +77,7 @@ typedef struct mij_encoder_params {
    * optimized_huffman is implied. */
   int progressive;
 } mij_encoder_params;
+#define MIJ_ENCODER_PARAMS_INIT {(uint32_t)sizeof(mij_encoder_params), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 
 /* Geometry derived from the parameters (useful to callers that shard). */
 typedef struct mij_geometry {
@@ -94,6 +102,10 @@ typedef struct mij_result {
 } mij_result;
 
 MIJ_API const char *mij_version(void);
+MIJ_API int mij_abi_version(void);   /* MIJ_ABI_VERSION the library was built with */
+/* SHA-256 (hex) over the sources, headers and compile flags this binary was built from (nvjpeg_imagecompressor_amd/build.py
+ * source_hash()): lets a deployment check that the .so it ships matches the tree. */
+MIJ_API const char *mij_source_hash(void);
 MIJ_API int mij_device_count(void);
 
 /* initCompressEnv (ImageCompressorImpl.cu:19-45): create handles, push parameters, allocate device workspace. */
@@ -178,6 +190,10 @@ MIJ_API int mij_decode_info(const uint8_t *jpeg, size_t jpeg_bytes, int *width, 
 MIJ_API int mij_decode_device(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, void *d_dst, size_t pitch,
                               size_t plane_stride, int output_format, void *stream);
 MIJ_API int mij_decode_sync(mij_decoder *dec, float *device_ms);
+/* Device time in ms of the last completed decode on this handle (what the reference means to print as
+ * "=> Decode Cost time", ImageCompressorImpl.cu:368-373, where the start event is never recorded), and the handle's device. */
+MIJ_API int mij_decode_last_ms(const mij_decoder *dec, float *device_ms);
+MIJ_API int mij_decoder_device(const mij_decoder *dec);
 /* DecodeWorker end to end (ImageCompressorImpl.cu:311-385): host JPEG bytes -> host pixels (one D2H, already interleaved). */
 MIJ_API int mij_decode_host(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t *dst, size_t pitch,
                             int output_format, int *width, int *height);
@@ -191,7 +207,10 @@ MIJ_API int mij_residual_device(const void *d_a, const void *d_b, void *d_out, s
  *   encode:  J1 = enc(I);  D = dec(J1);  R = clip(I - D + 128);  J2 = enc(R)          (same quality / sampling for both layers)
  *   decode:  I' = clip(dec(J1) + dec(J2) - 128)
  * `primary` / `secondary` are caller buffers; *primary_bytes / *secondary_bytes hold their capacities on entry and the
- * file sizes on return (MIJ_ERR_OVERFLOW, with the required sizes stored, if either is too small). */
+ * file sizes on return. MIJ_ERR_OVERFLOW if either is too small: *primary_bytes then holds the size the first layer needs,
+ * *secondary_bytes the size the second layer needs (0 if the first layer already did not fit and the second was not coded);
+ * grow the buffers and call again. A residual image is close to noise: at high quality with dense restart markers a layer
+ * can exceed the raw image size. Encoder and decoder must be on the same device. */
 MIJ_API int mij_secondary_encode_host(mij_encoder *enc, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride,
                                       int input_format, uint8_t *primary, size_t *primary_bytes, uint8_t *secondary,
                                       size_t *secondary_bytes);

@@ -18,20 +18,27 @@ STAGE_NAMES = ("transform", "statistics", "tables", "entropy", "scan", "compact"
 
 # every symbol include/mi_jpeg.h declares (tests/test_abi.py checks the library exports all of them)
 EXPORTS = (
-    "mij_version", "mij_device_count", "mij_encoder_create", "mij_encoder_destroy", "mij_encoder_geometry",
+    "mij_version", "mij_abi_version", "mij_source_hash", "mij_device_count", "mij_encoder_create", "mij_encoder_destroy", "mij_encoder_geometry",
     "mij_last_error", "mij_encode_device", "mij_encode_transform", "mij_encode_entropy", "mij_histogram_device",
     "mij_set_histogram_buffer", "mij_encode_result", "mij_retrieve_bitstream", "mij_encode_host",
     "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
     "mij_synth_image_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
     "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device", "mij_host_alloc", "mij_host_free",
-    "mij_secondary_encode_host", "mij_secondary_decode_host",
+    "mij_secondary_encode_host", "mij_secondary_decode_host", "mij_decode_last_ms", "mij_decoder_device",
 )
 
 
 class EncoderParams(C.Structure):
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("optimized_huffman", C.c_int),
+    """mij_encoder_params (include/mi_jpeg.h). struct_size is filled in by __init__: pass the other fields only."""
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("optimized_huffman", C.c_int),
                 ("css", C.c_int), ("restart_interval", C.c_int), ("device", C.c_int),
                 ("strip_mcu_row0", C.c_int), ("strip_mcu_rows", C.c_int), ("progressive", C.c_int)]
+
+    def __init__(self, *args, **kw):
+        if "struct_size" in kw:
+            super().__init__(*args, **kw)
+        else:
+            super().__init__(C.sizeof(EncoderParams), *args, **kw)
 
 
 class Geometry(C.Structure):
@@ -128,6 +135,10 @@ def load():
     L.mij_decode_sync.argtypes = [vp, C.POINTER(C.c_float)]
     L.mij_decode_host.argtypes = [vp, vp, sz, vp, sz, C.c_int, ip, ip]
     L.mij_residual_device.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    L.mij_decode_last_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mij_decoder_device.argtypes = [vp]
+    L.mij_abi_version.restype = C.c_int
+    L.mij_source_hash.restype = C.c_char_p
     _lib = L
     return L
 

@@ -1,6 +1,7 @@
 // ImageCompressor.cpp -- facade implementation over the mi_jpeg C ABI (see ImageCompressor.h for the contract).
-#include "ImageCompressor.h"
+#include "../../include/ImageCompressor.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -9,7 +10,7 @@
 
 class NvjpegCompressRunnerImpl {
  public:
-  mij_encoder_params p{};
+  mij_encoder_params p = MIJ_ENCODER_PARAMS_INIT;
   mij_encoder *enc = nullptr;
   mij_decoder *dec = nullptr;
   bool verbose = true;
@@ -97,9 +98,11 @@ cv::Mat NvjpegCompressRunner::decode(std::string image_path, int *run_state) {
     int w = 0, h = 0;
     if (mij_decode_info(data.data(), data.size(), &w, &h, nullptr, nullptr) == MIJ_OK) {
       cv::Mat m(h, w, CV_8UC3);
-      if (mij_decode_host(compressor->dec, data.data(), data.size(), m.ptr<unsigned char>(0), m.step, MIJ_INPUT_BGRI, &w, &h) == MIJ_OK)
+      if (mij_decode_host(compressor->dec, data.data(), data.size(), m.ptr<unsigned char>(0), m.step, MIJ_INPUT_BGRI, &w, &h) == MIJ_OK) {
         result = m;
-      else
+        float dms = 0;   // reference ImageCompressorImpl.cu:373 (whose start event is never recorded; this one is measured)
+        if (compressor->verbose && mij_decode_last_ms(compressor->dec, &dms) == MIJ_OK) std::cout << "=> Decode Cost time : " << dms << "ms" << std::endl;
+      } else
         compressor->err = mij_decoder_last_error(compressor->dec);
     } else {
       compressor->err = mij_decoder_last_error(nullptr);
@@ -120,13 +123,20 @@ std::vector<unsigned char> NvjpegCompressRunner::secondaryCompress(cv::Mat image
   } else if (image.empty() || image.type() != CV_8UC3 || image.cols != compressor->p.width || image.rows != compressor->p.height) {
     std::cerr << "[ERROR] secondaryCompress(): image must be CV_8UC3 " << compressor->p.width << "x" << compressor->p.height << std::endl;
   } else {
-    const size_t cap = (size_t)image.cols * image.rows * 3 + 65536;     // a JPEG at any quality stays below the raw size + headers
-    primary.resize(cap); secondary.resize(cap);
-    size_t n1 = cap, n2 = cap;
-    if (mij_secondary_encode_host(compressor->enc, compressor->dec, image.ptr<unsigned char>(0), image.step, 0, MIJ_INPUT_BGRI, primary.data(),
-                                  &n1, secondary.data(), &n2) == MIJ_OK) {
-      primary.resize(n1); secondary.resize(n2);
-    } else {
+    // Start from a generous guess and let the library say what it needs: a JPEG is usually far below the raw size, but a
+    // residual image is close to noise and, at q100 with dense restart markers, a layer can exceed it (MIJ_ERR_OVERFLOW
+    // then reports the required sizes).
+    size_t cap1 = (size_t)image.cols * image.rows * 3 / 2 + 65536, cap2 = cap1;
+    int rc = MIJ_ERR_OVERFLOW;
+    for (int attempt = 0; attempt < 4 && rc == MIJ_ERR_OVERFLOW; attempt++) {
+      primary.resize(cap1); secondary.resize(cap2);
+      size_t n1 = cap1, n2 = cap2;
+      rc = mij_secondary_encode_host(compressor->enc, compressor->dec, image.ptr<unsigned char>(0), image.step, 0, MIJ_INPUT_BGRI, primary.data(),
+                                     &n1, secondary.data(), &n2);
+      if (rc == MIJ_OK) { primary.resize(n1); secondary.resize(n2); }
+      else if (rc == MIJ_ERR_OVERFLOW) { cap1 = std::max(cap1, n1 + n1 / 8 + 4096); cap2 = std::max(cap2, n2 + n2 / 8 + 4096); if (n2 == 0) cap2 = std::max(cap2, cap1); }
+    }
+    if (rc != MIJ_OK) {
       compressor->err = mij_last_error(compressor->enc);
       primary.clear(); secondary.clear();
     }

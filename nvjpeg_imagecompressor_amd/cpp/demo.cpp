@@ -8,7 +8,7 @@
 #include <cstring>
 #include <string>
 
-#include "ImageCompressor.h"
+#include "../../include/ImageCompressor.h"
 
 static void printState(int run_state) { std::cout << (run_state == 1 ? "[INFO] Successful." : "[INFO] Failed.") << std::endl; }
 

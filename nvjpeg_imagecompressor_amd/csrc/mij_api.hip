@@ -5,6 +5,7 @@
 #include "mij_internal.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -137,7 +138,12 @@ static int choose_restart_interval(int mcux, int bpm) {
 
 extern "C" {
 
-const char *mij_version(void) { return "mi_jpeg 0.1 (gfx950)"; }
+const char *mij_version(void) { return "mi_jpeg 0.2 (gfx950)"; }
+int mij_abi_version(void) { return MIJ_ABI_VERSION; }
+#ifndef MIJ_SOURCE_HASH
+#define MIJ_SOURCE_HASH "unknown"
+#endif
+const char *mij_source_hash(void) { return MIJ_SOURCE_HASH; }
 
 int mij_device_count(void) {
   int n = 0;
@@ -171,9 +177,18 @@ void mij_encoder_destroy(mij_encoder *e) {
   delete e;
 }
 
-int mij_encoder_create(const mij_encoder_params *p, mij_encoder **out) {
-  if (!p || !out) return fail(nullptr, MIJ_ERR_INVALID_ARG, "null argument");
+int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
+  if (!p_in || !out) return fail(nullptr, MIJ_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
+  // The caller's struct may be older (shorter) than this library's: copy only what it has, zero the rest, and refuse sizes
+  // that match no layout this library knows (a caller that never set struct_size lands here too: width is not a size).
+  constexpr size_t kV1 = offsetof(mij_encoder_params, progressive);       // ABI 1 + struct_size: no `progressive`
+  if (p_in->struct_size != sizeof(mij_encoder_params) && p_in->struct_size != kV1)
+    return fail(nullptr, MIJ_ERR_INVALID_ARG, "mij_encoder_params.struct_size matches no known layout (set it to sizeof(mij_encoder_params))");
+  mij_encoder_params pcopy{};
+  memcpy(&pcopy, p_in, p_in->struct_size);
+  pcopy.struct_size = (uint32_t)sizeof(mij_encoder_params);
+  const mij_encoder_params *p = &pcopy;
   int hs, vs;
   if (p->width <= 0 || p->height <= 0 || p->width > 65535 || p->height > 65535)
     return fail(nullptr, MIJ_ERR_INVALID_ARG, "width/height must be in 1..65535");
@@ -666,6 +681,7 @@ int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *s
   if (!e || !dec || !src || !primary || !primary_bytes || !secondary || !secondary_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
   const Geom &g = e->g;
   if (g.mcu_first != 0 || !g.last_strip) return fail(e, MIJ_ERR_INVALID_ARG, "secondary compression works on whole images");
+  if (mij_decoder_device(dec) != e->p.device) return fail(e, MIJ_ERR_INVALID_ARG, "encoder and decoder are on different devices");
   const uint8_t *j1 = nullptr; size_t n1 = 0;
   int rc = mij_encode_host(e, src, pitch, plane_stride, fmt, &j1, &n1);      // J1; the image stays in e->d_src
   if (rc) return rc;

@@ -39,6 +39,7 @@ struct mij_decoder {
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0{}, ev1{};
   bool ev_ok = false, issued = false;
+  float last_ms = -1.f;
 };
 
 static thread_local std::string g_dec_err;
@@ -65,6 +66,7 @@ struct Parsed {
   int W = 0, H = 0, hs = 0, vs = 0, ri = 0, ncomp = 0;
   bool progressive = false;
   int comp_id[3] = {0, 0, 0};
+  bool have_sof = false;
   DecTables t{};
   bool have_tab[4] = {false, false, false, false};
   size_t scan_off = 0;         // first scan's data (fast path)
@@ -110,6 +112,10 @@ static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why, s
         k += 65;
       }
     } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      // one frame per file (libjpeg: JERR_SOF_DUPLICATE). Every scan descriptor is frozen from the frame in force at its
+      // SOS and the device buffers are sized from the frame: a second SOFn would let scans index outside them.
+      if (o.have_sof) { why = "duplicate SOF marker"; return MIJ_ERR_BAD_STREAM; }
+      o.have_sof = true;
       if (pl < 6 || s[0] != 8) { why = "only 8-bit samples"; return MIJ_ERR_BAD_STREAM; }
       o.progressive = m == 0xC2;
       o.ncomp = s[5];
@@ -135,7 +141,13 @@ static int parse_jpeg(const uint8_t *p, size_t n, Parsed &o, std::string &why, s
         const int t = th * 2 + tc;
         int cnt = 0;
         for (int l = 1; l <= 16; l++) cnt += s[k + l];
-        if (cnt > 256 || k + 17 + (size_t)cnt > pl) { why = "bad DHT"; return MIJ_ERR_BAD_STREAM; }
+        if (cnt < 1 || cnt > 256 || k + 17 + (size_t)cnt > pl) { why = "bad DHT"; return MIJ_ERR_BAD_STREAM; }
+        // The code counts must describe a prefix code (libjpeg jdhuff.c jpeg_make_d_derived_tbl: JERR_BAD_HUFF_TABLE): at
+        // every length l the codes assigned so far must fit l bits. Otherwise `code << (9 - l)` below runs past look[]
+        // and the device kernels would index vals[] out of range.
+        { int c2 = 0; bool ok = true;
+          for (int l = 1; l <= 16; l++) { c2 += s[k + l]; if (c2 > (1 << l)) ok = false; c2 <<= 1; }
+          if (!ok) { why = "bad DHT (code counts are not a prefix code)"; return MIJ_ERR_BAD_STREAM; } }
         // canonical codes -> look-ahead + slow-path tables
         memset(o.t.look[t], 0, sizeof o.t.look[t]);
         memcpy(o.t.vals[t], s + k + 17, (size_t)cnt);
@@ -422,6 +434,14 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
         for (int x = 0; x < a.ncomp; x++) for (int y = 0; y < b.ncomp; y++) comp |= a.comp[x] == b.comp[y];
         if (comp && a.Ss <= b.Se && b.Ss <= a.Se && (j & 3) != (i & 3)) DHIP(d, hipStreamWaitEvent(q, d->scan_ev[j], 0));
       }
+      {   // backstop: the scan's block grid must lie inside the frame the coefficient buffer was sized for
+        const ScanDesc &b = sc.sd;
+        const int gw = b.ncomp > 1 ? g.mcux : (ps.ncomp == 1 || b.comp[0] != 0 ? g.mcux : g.mcux * g.hs);
+        const int gh = b.ncomp > 1 ? g.mcuy : (ps.ncomp == 1 || b.comp[0] != 0 ? g.mcuy : g.mcuy * g.vs);
+        bool ok = b.bw >= 1 && b.bh >= 1 && b.bw <= gw && b.bh <= gh && b.nmcu == (long long)b.bw * b.bh && b.ncomp >= 1 && b.ncomp <= ps.ncomp;
+        for (int c = 0; c < b.ncomp && ok; c++) ok = b.comp[c] >= 0 && b.comp[c] < ps.ncomp;
+        if (!ok) return dfail(d, MIJ_ERR_BAD_STREAM, "scan geometry does not match the frame");
+      }
       const uint8_t *base = d->d_scan + (sc.off - data_off);
       const long long ns = sc.sd.ri > 0 ? (sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri : 1;
       unsigned long long *seg = d->d_scan_ws + o_seg[i];
@@ -448,10 +468,20 @@ int mij_decode_sync(mij_decoder *d, float *device_ms) {
   DHIP(d, hipStreamSynchronize(d->last_stream));
   uint32_t flags[2] = {0, 0};
   DHIP(d, hipMemcpy(flags, d->d_flags, sizeof flags, hipMemcpyDeviceToHost));
-  if (device_ms) { float t = 0; if (hipEventElapsedTime(&t, d->ev0, d->ev1) != hipSuccess) t = -1.f; *device_ms = t; }
+  { float t = 0; if (hipEventElapsedTime(&t, d->ev0, d->ev1) != hipSuccess) t = -1.f; d->last_ms = t; }
+  if (device_ms) *device_ms = d->last_ms;
   if (flags[1]) return dfail(d, MIJ_ERR_BAD_STREAM, "corrupt entropy-coded data");
   return MIJ_OK;
 }
+
+int mij_decode_last_ms(const mij_decoder *d, float *device_ms) {
+  if (!d || !device_ms) return MIJ_ERR_INVALID_ARG;
+  if (d->last_ms < 0) return MIJ_ERR_NOT_READY;
+  *device_ms = d->last_ms;
+  return MIJ_OK;
+}
+
+int mij_decoder_device(const mij_decoder *d) { return d ? d->device : -1; }
 
 int mij_decode_host(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t *dst, size_t pitch, int output_format, int *width,
                     int *height) {

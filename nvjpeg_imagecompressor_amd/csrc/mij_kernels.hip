@@ -14,6 +14,10 @@
 //   D2 k_huff_decode       lane per restart interval (fallback)                                        (k_decode.inc)
 //   D2s k_scan_decode      progressive / multi-scan / greyscale scans                                  (k_decode_scans.inc)
 //   D3 k_idct, D4 k_upsample_color[8], k_residual   IDCT, upsampling + colour, difference map          (k_decode.inc)
+// Bit-identity with stock JPEG codecs means following their integer procedures: the "islow" FDCT / IDCT factorisation and
+// constants, the colour / downsampling rounding rules, the quantiser and the optimal-table and progressive procedures are
+// those of the Independent JPEG Group's libjpeg and of libjpeg-turbo, re-implemented here for wave-64 hardware.
+// This software is based in part on the work of the Independent JPEG Group.
 // No MFMA anywhere: this path is integer/byte work bounded by HBM and by VALU issue, not a contraction.
 // Wavefront = 64 lanes throughout.
 #include "mij_internal.h"

@@ -189,6 +189,11 @@ class Decoder:
         self._check(self._L.mij_decode_device(self._h, C.c_void_p(d_jpeg), nbytes, C.c_void_p(d_ptr), pitch, plane_stride,
                                               _FMT[fmt], C.c_void_p(stream)), "mij_decode_device")
 
+    def last_ms(self):
+        ms = C.c_float()
+        self._check(self._L.mij_decode_last_ms(self._h, C.byref(ms)), "mij_decode_last_ms")
+        return float(ms.value)
+
     def sync(self):
         ms = C.c_float()
         self._check(self._L.mij_decode_sync(self._h, C.byref(ms)), "mij_decode_sync")
@@ -279,6 +284,8 @@ class NvjpegCompressRunner:
             if self._dec is None:
                 raise MiJpegError("decode() before buildDecodeEnv()")
             result = self._dec.decode_host(data, "bgr")
+            if self.verbose:
+                print("=> Decode Cost time : %gms" % self._dec.last_ms())   # reference ImageCompressorImpl.cu:373
         except MiJpegError as e:
             print("[ERROR] Exception caught : %s" % e)
             result = None
@@ -316,13 +323,19 @@ class NvjpegCompressRunner:
             image = np.ascontiguousarray(image, np.uint8)
             if image.shape != (self.height, self.width, 3):
                 raise MiJpegError("image must be uint8 %dx%dx3" % (self.height, self.width))
-            cap = image.size + 65536
-            b1, b2 = np.empty(cap, np.uint8), np.empty(cap, np.uint8)
-            n1, n2 = C.c_size_t(cap), C.c_size_t(cap)
+            # a residual image is close to noise: a layer can exceed the raw size (MIJ_ERR_OVERFLOW reports what is needed)
+            cap1 = cap2 = image.size // 2 + 65536
             L = self._enc._L
-            _lib.check(L.mij_secondary_encode_host(self._enc._h, self._dec._h, image.ctypes.data, self.width * 3, 0, _FMT["bgr"],
-                                                   b1.ctypes.data, C.byref(n1), b2.ctypes.data, C.byref(n2)), self._enc._h,
-                       "mij_secondary_encode_host")
+            for _ in range(4):
+                b1, b2 = np.empty(cap1, np.uint8), np.empty(cap2, np.uint8)
+                n1, n2 = C.c_size_t(cap1), C.c_size_t(cap2)
+                rc = L.mij_secondary_encode_host(self._enc._h, self._dec._h, image.ctypes.data, self.width * 3, 0, _FMT["bgr"],
+                                                 b1.ctypes.data, C.byref(n1), b2.ctypes.data, C.byref(n2))
+                if rc != -5:    # MIJ_ERR_OVERFLOW
+                    break
+                cap1 = max(cap1, n1.value + n1.value // 8 + 4096)
+                cap2 = max(cap2, n2.value + n2.value // 8 + 4096, cap1 if n2.value == 0 else 0)
+            _lib.check(rc, self._enc._h, "mij_secondary_encode_host")
             return b1[:n1.value].tobytes(), b2[:n2.value].tobytes(), 1
         except MiJpegError as e:
             print("[ERROR] Exception caught: %s" % e)

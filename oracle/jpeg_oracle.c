@@ -15,8 +15,17 @@
  * IJG libjpeg 9d for the 4:4:0 and 4:1:1 samplings; tests/test_oracle_pin.py compares whole files
  * byte-for-byte with those stock encoders, and tests/golden/ holds the vectors.
  *
- * Everything here is written from the standard; no reference source is copied (there is none to copy: the
- * reference contains no JPEG arithmetic).
+ * Nothing here comes from the reference (it contains no JPEG arithmetic). ATTRIBUTION: bit-identity with the stock
+ * encoders is only possible by following their integer procedures, so several routines RESTATE code of the Independent
+ * JPEG Group's libjpeg and of libjpeg-turbo -- fdct_islow (jfdctint.c: the Loeffler-Ligtenberg-Moschytz factorisation
+ * with the same 13-bit FIX_* constants and descale points), the colour conversion and downsampling rounding rules
+ * (jccolor.c, jcsample.c), the quantiser (jcdctmgr.c), the optimal-table construction incl. length limiting (jchuff.c
+ * jpeg_gen_optimal_table), and the progressive scan script and coder (jcparam.c jpeg_simple_progression, jcphuff.c).
+ *   This software is based in part on the work of the Independent JPEG Group.
+ *   libjpeg: Copyright (C) 1991-2020, Thomas G. Lane, Guido Vollbeding.
+ *   libjpeg-turbo: Copyright (C) 2009-2024 D. R. Commander et al.; distributed under the IJG licence and the
+ *   Modified (3-clause) BSD licence (see libjpeg-turbo's LICENSE.md / README.ijg for the full terms: the IJG
+ *   licence permits use, copying, modification and distribution provided this acknowledgement is retained).
  */
 #include <stdint.h>
 #include <stdlib.h>

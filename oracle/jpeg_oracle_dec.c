@@ -12,6 +12,13 @@
  *
  * Handles baseline sequential (SOF0) 3-component YCbCr files with chroma 1x1 and luma h x v in {1,2,4} x {1,2}
  * (everything this project's encoder writes, with or without restart intervals), Huffman tables from the file.
+ *
+ * ATTRIBUTION: the inverse DCT, the fancy upsampling filters and the YCbCr->RGB tables RESTATE the integer procedures of
+ * the Independent JPEG Group's libjpeg / libjpeg-turbo (jidctint.c, jdsample.c, jdcolor.c, jdhuff.c), because pixel
+ * identity with the stock decoder requires exactly their arithmetic.
+ *   This software is based in part on the work of the Independent JPEG Group.
+ *   libjpeg: Copyright (C) 1991-2020, Thomas G. Lane, Guido Vollbeding. libjpeg-turbo: Copyright (C) 2009-2024
+ *   D. R. Commander et al., IJG licence + Modified (3-clause) BSD licence (libjpeg-turbo LICENSE.md / README.ijg).
  */
 #include <stdint.h>
 #include <stdlib.h>

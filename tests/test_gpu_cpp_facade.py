@@ -1,4 +1,4 @@
-"""The C++ drop-in class (nvjpeg_imagecompressor_amd/cpp/ImageCompressor.h, same surface as the reference's
+"""The C++ drop-in class (include/ImageCompressor.h, same surface as the reference's
 src/ImageCompressorDll/ImageCompressor.h:22-42) driven by the demo that follows the reference main.cpp sequence."""
 import os
 import subprocess
@@ -34,6 +34,7 @@ def test_demo_sequence_matches_oracle(mij, oracle, tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert r.stdout.count("[INFO] Successful.") == 4      # 2 compress + 2 decode
         assert "=> Compress Cost time" in r.stdout and "NvjpegCompressRunner Compress Func Cost Time" in r.stdout
+        assert r.stdout.count("=> Decode Cost time : ") == 2 and "NvjpegCompressRunner Decode Func Cost Time" in r.stdout   # reference .cu:373, .cpp:85
         assert "Delete NvjpegCompressRunnerImpl Successfully" in r.stdout
         for i, im in enumerate(imgs):
             got = open("%s_%d.jpeg" % (out, i + 1), "rb").read()

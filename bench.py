@@ -6,8 +6,11 @@ Huffman (reference README.md:48 config), device-resident input -> device-residen
 
 A "step" is one whole encode of the image. At N > 1 the image is cut into restart-interval-aligned strips of MCU
 rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
-of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes, gather of strip bitstreams to
-rank 0. Total work is fixed as N grows => "scaling": "strong".  Rank 0 prints ONE JSON line.
+of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes (device to device), and every
+rank > 0 PUTS its strip into the file rank 0 assembles (peer-mapped buffer, one xGMI link per rank) at the offset a
+kernel derives from the gathered sizes; three images in flight per rank, no host wait in a step (sharded.DevicePipeline;
+RCCL send/recv with host-side sizes if the peer mapping is unavailable). Total work is fixed as N grows => "scaling":
+"strong".  Rank 0 prints ONE JSON line.
 """
 import argparse
 import io
@@ -27,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=W_IMG)
     ap.add_argument("--height", type=int, default=H_IMG)
     ap.add_argument("--css", default=CSS_NAME)
@@ -44,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1000, help="rows per CPU-baseline strip (one strip per core)")
+    ap.add_argument("--cpu-one-core-rows", type=int, default=0, help="rows of the 1-core CPU sample (0 = the whole image, SURVEY 8d (i))")
+    ap.add_argument("--gather", default=os.environ.get("MIJ_SHARDED_GATHER", "put"), choices=["put", "sendrecv"],
+                    help="N > 1: put = strips written into rank 0's peer-mapped buffer, sizes stay on the device (default); "
+                         "sendrecv = host-side sizes + RCCL send/recv (also the automatic fallback)")
     return ap.parse_args()
 
 
@@ -67,16 +74,17 @@ def _cpu_share():
 
 
 def cpu_baselines(args, optimize, restart_interval):
-    """Bounded CPU sample of the same workload on the host cores: (a) the oracle C port, (b) libjpeg-turbo via Pillow.
-    One strip of the synthetic image per core; runs in a separate interpreter (tools/cpu_baseline.py) so that its
-    process pool never forks a process that holds a HIP context."""
+    """Bounded CPU sample of the same workload on the host cores (tools/cpu_baseline.py): libjpeg-turbo via
+    Pillow on all cores and on one core, the oracle C port, and IJG libjpeg 9d for 4:4:0 / 4:1:1. Runs in a separate
+    interpreter so that its process pool never forks a process that holds a HIP context."""
     import subprocess
     cores = int(os.environ.get("MIJ_BENCH_CORES", "0")) or _cpu_share()
     css = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5}[args.css]
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--width", str(args.width), "--height", str(args.height),
-           "--rows", str(args.cpu_sample_rows), "--cores", str(cores), "--quality", str(args.quality), "--css", str(css),
+           "--rows", str(args.cpu_sample_rows), "--one-core-rows", str(args.cpu_one_core_rows), "--cores", str(cores),
+           "--quality", str(args.quality), "--css", str(css),
            "--optimize", str(int(optimize)), "--ri", str(restart_interval)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     if r.returncode:
         raise RuntimeError("cpu baseline failed: " + r.stderr[-500:])
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -110,44 +118,63 @@ def main():
     W, H = args.width, args.height
 
     # ---- strip partition (pure arithmetic, no communication) + this rank's pixels --------------------------------
-    enc = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
-                                         restart_interval=args.restart_interval, progressive=args.progressive)
-    geo = enc.geometry
+    # One handle per image in flight: 2 on one GPU (the host collects image i-1 while image i runs), DEPTH on N GPUs.
+    whole_geo, r0_, r1_ = sharded.strip_rows(W, H, args.quality, optimize, args.css, rank, world, args.restart_interval)
+    want_put = world > 1 and args.gather == "put" and os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" and not args.progressive
+    n_handles = 1 if args.progressive or (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1") else (sharded.DEPTH if want_put else 2)
+    encs = [sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
+                                           restart_interval=args.restart_interval, progressive=args.progressive) for _ in range(n_handles)]
+    enc = encs[0]                     # None: this rank owns no strip (more ranks than restart-aligned strips)
+    geo = enc.geometry if enc is not None else dict(whole_geo, strip_y0=0, strip_rows=0)
     y0, rows = geo["strip_y0"], geo["strip_rows"]
-    d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
-    strip = sharded.HipStripEncoder(torch, enc, d_img, args.fmt)
-    enc.enable_timing(True)
+    d_img, strips = None, [None] * n_handles
+    if enc is not None:
+        d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
+        mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
+        strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt) for e in encs]
+    strip = strips[0]
     torch.cuda.synchronize()
 
-    copy_gbs = hbm_copy_ceiling(torch, dev) if rank == 0 else None
-    cache, stage_acc = {}, {}
+    copy_gbs, copy_lib_gbs = hbm_copy_ceiling(torch, mij, dev) if rank == 0 else (None, None)
+    cache, stage_acc = {"device": dev}, {}
 
-    # Two encoder handles alternate, so that an image's kernels are queued while the host collects the previous image's
-    # result (size, stage times). Every step still produces a complete file inside the timed region.
-    #  * One GPU: what disappears is the GPU idling during the host's round trip (~35 us of a 1.5 ms step).
-    #  * N GPUs (sharded.StripPipeline): the gather of image i-1 to rank 0 and the host round trips for its strip sizes
-    #    overlap image i's kernels. MIJ_BENCH_NO_PIPELINE=1 falls back to one image at a time (sharded.encode_step).
-    pipelined = not args.progressive and not (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1")
-    strips = [strip]
-    if pipelined:
-        enc2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
-                                              restart_interval=args.restart_interval)
-        enc2.enable_timing(True)
-        strips.append(sharded.HipStripEncoder(torch, enc2, d_img, args.fmt))
+    # Images in flight. Every step still produces a complete file inside the timed region.
+    #  * One GPU: two handles alternate; what disappears is the GPU idling during the host's round trip for the result.
+    #  * N GPUs, "put" (sharded.DevicePipeline): three images in flight, sizes all-gathered device to device, strips written
+    #    straight into rank 0's peer-mapped buffer; no host wait inside a step. If the buffers cannot be mapped, or with
+    #    --gather sendrecv: sharded.StripPipeline (two in flight, sizes via the host, RCCL send/recv).
+    #    MIJ_BENCH_NO_PIPELINE=1: one image at a time (sharded.encode_step).
+    pipelined = n_handles > 1
+    gather_mode, pipe, dpipe = None, None, None
+    if world > 1:
+        gather_mode = "sendrecv"
+        if want_put:
+            targets = sharded.open_file_targets(torch, dist, strips if enc is not None else None, rank, world, dev_index, whole_geo)
+            if targets is not None:
+                dpipe = sharded.DevicePipeline(torch, dist, strips if enc is not None else None, targets, optimize, device=dev)
+                gather_mode = "put"
+        if dpipe is None and pipelined:
+            unit = sharded.rows_per_restart_unit(whole_geo["mcus_per_row"], whole_geo["restart_interval"])
+            if (whole_geo["mcu_rows"] + unit - 1) // unit < world:      # the same arithmetic on every rank: all of them stop
+                raise SystemExit("the send/recv pipeline needs a strip on every rank (more ranks than restart-aligned strips)")
+            pipe = sharded.StripPipeline(torch, dist, strips[:2], optimize)
+    timed_handles = [] if dpipe is not None else [e for e in encs if e is not None]
+    for e in timed_handles:
+        e.enable_timing(True)
     state = {"i": 0, "pending": None}
     streams = [torch.cuda.current_stream().cuda_stream] * 2
     if pipelined and world == 1 and args.two_streams:
         second = torch.cuda.Stream()
         streams = [streams[0], second.cuda_stream]
-    pipe = sharded.StripPipeline(torch, dist, strips, optimize) if (pipelined and world > 1) else None
 
     def record_times(e):
         for k, v in e.stage_times().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
 
     def collect(record):
+        if dpipe is not None:                     # completes every image in flight; rank 0 gets the last file
+            return dpipe.flush()
         if pipe is not None:                      # the last image of a multi-rank run
             prev = pipe.pending
             out = pipe.flush()
@@ -169,6 +196,9 @@ def main():
             if record:
                 record_times(enc)
             return out
+        if dpipe is not None:
+            dpipe.step()                          # enqueue only: no host wait, no result yet
+            return None
         if pipe is not None:
             prev = pipe.pending
             out = pipe.step()                     # issues this image, then completes the previous one
@@ -205,6 +235,19 @@ def main():
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     value = (W * H / 1e6) / (ms_per_step / 1e3)
+    steps_timed = args.steps
+    if dpipe is not None:
+        # The put pipeline records no per-stage events (nothing in it touches the host). For the stage table, code one more
+        # image the host-synchronised way, outside the timed region, with events on.
+        jpeg_keep = jpeg_t.clone() if jpeg_t is not None else None
+        if enc is not None:
+            enc.enable_timing(True)
+        sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+        if enc is not None:
+            record_times(enc)
+        steps_timed = 1
+        fence()
+        jpeg_t = jpeg_keep
 
     # Informational second figure (--also-two-streams; one GPU, headline path only): the same loop with the two images in flight on TWO HIP
     # streams, where one image's narrow kernels (DC statistics, tables, scan) and the wide kernels' tails overlap the other
@@ -234,7 +277,7 @@ def main():
     if rank == 0:
         jpeg = jpeg_t.cpu().numpy().tobytes()
         ratio = len(jpeg) / (3.0 * W * H)
-        stages = {k: v / args.steps for k, v in stage_acc.items()}
+        stages = {k: v / steps_timed for k, v in stage_acc.items()}
         strip_px = rows * W
         bpp = algorithmic_bytes_per_pixel(args.css, ratio)
         kname = {"transform": "k_transform", "entropy": "k_encode", "compact": "k_compact"}
@@ -268,9 +311,11 @@ def main():
                                    "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
-                       "images_in_flight": 2 if pipelined else 1, "streams": 2 if (pipelined and world == 1 and args.two_streams) else 1},
+                       "images_in_flight": n_handles, "gather": gather_mode,
+                       "streams": n_handles if dpipe is not None else (2 if (pipelined and world == 1 and args.two_streams) else 1)},
             "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
-            "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None, "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None,
+            "hbm_copy_ceiling_note": "own 16-B/lane copy kernel (k_copy16), read + write bytes; torch copy_ on the same box: %s GB/s" % (round(copy_lib_gbs, 1) if copy_lib_gbs else None), "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }
         if two_streams:
             out["two_streams"] = two_streams
@@ -278,13 +323,22 @@ def main():
             out["psnr_db"], out["psnr_note"] = _psnr_check(jpeg, W, H, args.fmt, d_img if world == 1 else None)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baselines(args, optimize, geo["restart_interval"])
-            out["cpu_baseline"] = dict(cb["port"], kind="port", impl="oracle/jpeg_oracle.c")
+            # The baseline north_star names is libjpeg-turbo on the box's host cores; kind "port" = the stock CPU library whose
+            # arithmetic oracle/ restates byte for byte (there is no oracle/_ref: the reference's nvJPEG cannot be built here).
             if "turbo" in cb:
-                out["cpu_libjpeg_turbo"] = dict(cb["turbo"], impl="libjpeg-turbo 3.1.4.1 via Pillow")
+                out["cpu_baseline"] = dict(cb["turbo"], kind="port", impl="libjpeg-turbo 3.1.4.1 via Pillow (SIMD), all host cores")
+                out["cpu_baseline_1core"] = dict(cb["turbo_1core"], impl="libjpeg-turbo 3.1.4.1 via Pillow, one core (the library's native mode)")
+            elif "ijg" in cb:
+                out["cpu_baseline"] = dict(cb["ijg"], kind="port", impl="IJG libjpeg 9d C API (non-SIMD; Pillow's libjpeg-turbo cannot write 4:4:0 / 4:1:1), all host cores")
+                if "ijg_1core" in cb:
+                    out["cpu_baseline_1core"] = dict(cb["ijg_1core"], impl="IJG libjpeg 9d C API (non-SIMD), one core")
+            else:
+                out["cpu_baseline"] = dict(cb["port"], kind="port", impl="oracle/jpeg_oracle.c")
+            out["cpu_oracle_port"] = dict(cb["port"], impl="oracle/jpeg_oracle.c (the checker, OpenMP-free, one strip per core)")
         print(json.dumps(out), flush=True)
-    enc.close()
-    if pipelined:
-        enc2.close()
+    for e in encs:
+        if e is not None:
+            e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -296,22 +350,32 @@ def bpp_stage_b(css):
     return 2.0 * (1.0 + f)
 
 
-def hbm_copy_ceiling(torch, dev):
-    """On-box streaming ceiling: device-to-device copy of 1 GiB, read + write bytes per second."""
+def hbm_copy_ceiling(torch, mij, dev):
+    """On-box streaming ceiling: device-to-device copy of 1 GiB with the library's own 16-B/lane copy kernel
+    (MI355X_MICROARCH.md quotes ~6.3 TB/s for a float4 copy), read + write bytes per second, timed with events on the stream
+    the kernel runs on. Second value: torch's copy_ of the same buffers, for reference (round 1 quoted that one)."""
     n = 1 << 30
     a = torch.empty(n, dtype=torch.uint8, device=dev)
     b = torch.empty_like(a)
-    for _ in range(2):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
+    a.zero_()
+    st = torch.cuda.current_stream()
+
+    def timed(fn, reps=10):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn()
+        e1.record(st)
+        e1.synchronize()
+        return 2 * n / (e0.elapsed_time(e1) * 1e-3 / reps) / 1e9
+
+    own = timed(lambda: mij.copy_bench_device(b.data_ptr(), a.data_ptr(), n, st.cuda_stream))
+    lib = timed(lambda: b.copy_(a))
     del a, b
     torch.cuda.empty_cache()
-    return 2 * n / dt / 1e9
+    return own, lib
 
 
 def measured_traffic(kernel, args, optimize, world):

@@ -113,6 +113,9 @@ MIJ_API int mij_encoder_create(const mij_encoder_params *params, mij_encoder **o
 /* destoryCompressEnv (ImageCompressorImpl.cu:47-65). NULL is a no-op. */
 MIJ_API void mij_encoder_destroy(mij_encoder *enc);
 MIJ_API int mij_encoder_geometry(const mij_encoder *enc, mij_geometry *out);
+/* The same geometry from the parameters alone: pure arithmetic, no device, nothing allocated (what a sharding host needs
+ * to cut strips before it creates its handle). */
+MIJ_API int mij_geometry_query(const mij_encoder_params *params, mij_geometry *out);
 MIJ_API const char *mij_last_error(const mij_encoder *enc);
 
 /* nvjpegEncodeImage (ImageCompressorImpl.cu:280): device-resident pixels -> device-resident bitstream, asynchronous
@@ -131,6 +134,26 @@ MIJ_API int mij_encode_entropy(mij_encoder *enc, void *stream);
 MIJ_API int mij_histogram_device(mij_encoder *enc, uint32_t **d_hist, size_t *count);
 /* Use caller-owned device memory (e.g. a framework tensor that a collective can reduce) for the statistics. */
 MIJ_API int mij_set_histogram_buffer(mij_encoder *enc, uint32_t *d_hist);
+
+/* ---- Strip sharding with sizes and offsets kept on the device (multi-GPU; the reference has no counterpart:
+ * one nvjpegEncodeImage call on one GPU, ImageCompressorImpl.cu:280). Per image and rank:
+ *   mij_encode_transform -> [all-reduce of the statistics] -> mij_encode_entropy_sizes(&d_slot)
+ *   -> [all-gather of the slots into d_sizes[world]] -> mij_encode_place(...)
+ * Nothing in that sequence waits on the host. Rank 0 assembles the file in its own output buffer (reserve room for the
+ * whole file with mij_encoder_reserve_output); ranks > 0 write their strip into it through a peer mapping
+ * (mij_ipc_export on rank 0, mij_ipc_open on the others) at byte offset sum(d_sizes[0..rank)). The file is complete on
+ * rank 0 once every rank's mij_encode_place has executed -- e.g. when a later collective on the same streams completes.
+ * mij_sharded_result waits for this handle's part and reports the file (rank 0) / the strip (others). */
+MIJ_API int mij_encode_entropy_sizes(mij_encoder *enc, uint64_t *d_size_slot, void *stream);
+MIJ_API int mij_encode_place(mij_encoder *enc, uint8_t *d_file_scan, size_t file_scan_capacity, const uint64_t *d_sizes, int rank,
+                             int world, void *stream);
+MIJ_API int mij_sharded_result(mij_encoder *enc, const uint64_t *d_sizes, int rank, int world, mij_result *out);
+MIJ_API int mij_encoder_reserve_output(mij_encoder *enc, size_t scan_capacity_bytes);
+MIJ_API int mij_output_buffer(mij_encoder *enc, void **d_buffer, size_t *scan_offset, size_t *scan_capacity);
+#define MIJ_IPC_HANDLE_BYTES 64
+MIJ_API int mij_ipc_export(const void *d_ptr, void *handle64);
+MIJ_API int mij_ipc_open(int device, const void *handle64, void **d_ptr);
+MIJ_API int mij_ipc_close(void *d_ptr);
 
 /* Waits for `stream` work issued by the last encode and reports where the bitstream is. */
 MIJ_API int mij_encode_result(mij_encoder *enc, mij_result *out);
@@ -219,6 +242,9 @@ MIJ_API int mij_secondary_decode_host(mij_decoder *dec, const uint8_t *primary, 
 
 /* Bench utility: fill device memory with rows [y0, y0+rows) of the SURVEY.md 8(d) synthetic image
  * (RGB or BGR interleaved). */
+/* Bench utility: the streaming-copy yardstick (16 B per lane, 4 loads in flight): read + write `bytes` each; all three
+ * arguments 16-byte aligned. */
+MIJ_API int mij_copy_bench_device(void *d_dst, const void *d_src, size_t bytes, void *stream);
 MIJ_API int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream);
 
 #ifdef __cplusplus

@@ -22,9 +22,11 @@ EXPORTS = (
     "mij_last_error", "mij_encode_device", "mij_encode_transform", "mij_encode_entropy", "mij_histogram_device",
     "mij_set_histogram_buffer", "mij_encode_result", "mij_retrieve_bitstream", "mij_encode_host",
     "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
-    "mij_synth_image_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
+    "mij_synth_image_device", "mij_copy_bench_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
     "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device", "mij_host_alloc", "mij_host_free",
     "mij_secondary_encode_host", "mij_secondary_decode_host", "mij_decode_last_ms", "mij_decoder_device",
+    "mij_geometry_query", "mij_encode_entropy_sizes", "mij_encode_place", "mij_sharded_result", "mij_encoder_reserve_output",
+    "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close",
 )
 
 
@@ -123,6 +125,7 @@ def load():
     L.mij_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.mij_debug_coefficients.argtypes = [vp, vp, sz]
     L.mij_debug_tables.argtypes = [vp, vp]
+    L.mij_copy_bench_device.argtypes = [vp, vp, sz, vp]
     L.mij_synth_image_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, sz, C.c_int, vp]
     L.mij_decoder_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.mij_decoder_destroy.argtypes = [vp]
@@ -135,6 +138,15 @@ def load():
     L.mij_decode_sync.argtypes = [vp, C.POINTER(C.c_float)]
     L.mij_decode_host.argtypes = [vp, vp, sz, vp, sz, C.c_int, ip, ip]
     L.mij_residual_device.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    L.mij_geometry_query.argtypes = [C.POINTER(EncoderParams), C.POINTER(Geometry)]
+    L.mij_encode_entropy_sizes.argtypes = [vp, vp, vp]
+    L.mij_encode_place.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, vp]
+    L.mij_sharded_result.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]
+    L.mij_encoder_reserve_output.argtypes = [vp, sz]
+    L.mij_output_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.mij_ipc_export.argtypes = [vp, vp]
+    L.mij_ipc_open.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.mij_ipc_close.argtypes = [vp]
     L.mij_decode_last_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mij_decoder_device.argtypes = [vp]
     L.mij_abi_version.restype = C.c_int

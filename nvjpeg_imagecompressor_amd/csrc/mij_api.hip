@@ -65,7 +65,7 @@ struct mij_encoder {
                              // who alternates two handles on one stream keeps the GPU busy while it collects a result
   bool ev_ok = false, timing = false, timed_run = false;
   float ms[MIJ_NUM_STAGE_TIMES]{};
-  bool transformed = false, issued = false, static_tables_ready = false, wait_event = false;
+  bool transformed = false, issued = false, static_tables_ready = false, wait_event = false, sharded_pending = false;
   hipStream_t last_stream = nullptr;
 };
 
@@ -177,15 +177,24 @@ void mij_encoder_destroy(mij_encoder *e) {
   delete e;
 }
 
-int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
-  if (!p_in || !out) return fail(nullptr, MIJ_ERR_INVALID_ARG, "null argument");
-  *out = nullptr;
+// Validates the parameters and derives the geometry (pure arithmetic: no device needed). `p` receives the normalised copy.
+static int derive_geometry(const mij_encoder_params *p_in, mij_encoder_params &pcopy, Geom &g);
+
+int mij_geometry_query(const mij_encoder_params *p_in, mij_geometry *o) {
+  if (!p_in || !o) return fail(nullptr, MIJ_ERR_INVALID_ARG, "null argument");
+  mij_encoder e;            // only p / g are used
+  int rc = derive_geometry(p_in, e.p, e.g);
+  if (rc) return rc;
+  return mij_encoder_geometry(&e, o);
+}
+
+static int derive_geometry(const mij_encoder_params *p_in, mij_encoder_params &pcopy, Geom &g) {
   // The caller's struct may be older (shorter) than this library's: copy only what it has, zero the rest, and refuse sizes
   // that match no layout this library knows (a caller that never set struct_size lands here too: width is not a size).
   constexpr size_t kV1 = offsetof(mij_encoder_params, progressive);       // ABI 1 + struct_size: no `progressive`
   if (p_in->struct_size != sizeof(mij_encoder_params) && p_in->struct_size != kV1)
     return fail(nullptr, MIJ_ERR_INVALID_ARG, "mij_encoder_params.struct_size matches no known layout (set it to sizeof(mij_encoder_params))");
-  mij_encoder_params pcopy{};
+  pcopy = mij_encoder_params{};
   memcpy(&pcopy, p_in, p_in->struct_size);
   pcopy.struct_size = (uint32_t)sizeof(mij_encoder_params);
   const mij_encoder_params *p = &pcopy;
@@ -194,6 +203,39 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
     return fail(nullptr, MIJ_ERR_INVALID_ARG, "width/height must be in 1..65535");
   if (p->quality < 1 || p->quality > 100) return fail(nullptr, MIJ_ERR_INVALID_ARG, "quality must be in 1..100");
   if (css_factors(p->css, hs, vs)) return fail(nullptr, MIJ_ERR_INVALID_ARG, "unsupported chroma subsampling");
+  g = Geom{};
+  g.W = p->width; g.H = p->height; g.hs = hs; g.vs = vs; g.nl = hs * vs; g.bpm = g.nl + 2;
+  g.mcux = (g.W + 8 * hs - 1) / (8 * hs);
+  g.mcuy = (g.H + 8 * vs - 1) / (8 * vs);
+  g.wib0 = (g.W + 7) / 8; g.hib0 = (g.H + 7) / 8;
+  g.crows = (g.H + vs - 1) / vs;
+  g.quality = p->quality;
+  int ri = p->restart_interval;
+  if (ri == MIJ_RESTART_AUTO) ri = choose_restart_interval(g.mcux, g.bpm);
+  if (ri < 1 || ri > 65535) return fail(nullptr, MIJ_ERR_INVALID_ARG, "restart_interval must be 1..65535 MCUs (or MIJ_RESTART_AUTO)");
+  g.ri = ri;
+  int row0 = p->strip_mcu_row0, rows = p->strip_mcu_rows;
+  if (rows == 0) { row0 = 0; rows = g.mcuy; }
+  if (row0 < 0 || rows < 0 || row0 + rows > g.mcuy) return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip outside the image");
+  g.mcu_first = (long long)row0 * g.mcux;
+  g.mcu_count = (long long)rows * g.mcux;
+  if (g.mcu_first % ri) return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not start on a restart-interval boundary");
+  g.last_strip = (row0 + rows == g.mcuy);
+  if (!g.last_strip && (g.mcu_count % ri)) return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not end on a restart-interval boundary");
+  g.y_origin = row0 * 8 * vs;
+  geom_finish(g);
+  if (p->progressive && (row0 != 0 || rows != g.mcuy)) return fail(nullptr, MIJ_ERR_INVALID_ARG, "progressive output is for whole images (no strips)");
+  return MIJ_OK;
+}
+
+int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
+  if (!p_in || !out) return fail(nullptr, MIJ_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  mij_encoder_params pcopy;
+  Geom g0;
+  int rc0 = derive_geometry(p_in, pcopy, g0);
+  if (rc0) return rc0;
+  const mij_encoder_params *p = &pcopy;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, MIJ_ERR_NO_DEVICE, "no HIP device: mi_jpeg has no CPU fallback");
@@ -203,28 +245,9 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   mij_encoder *e = new (std::nothrow) mij_encoder();
   if (!e) return fail(nullptr, MIJ_ERR_ALLOC, "out of host memory");
   e->p = *p;
+  e->g = g0;
   Geom &g = e->g;
-  g.W = p->width; g.H = p->height; g.hs = hs; g.vs = vs; g.nl = hs * vs; g.bpm = g.nl + 2;
-  g.mcux = (g.W + 8 * hs - 1) / (8 * hs);
-  g.mcuy = (g.H + 8 * vs - 1) / (8 * vs);
-  g.wib0 = (g.W + 7) / 8; g.hib0 = (g.H + 7) / 8;
-  g.crows = (g.H + vs - 1) / vs;
-  g.quality = p->quality;
-  int ri = p->restart_interval;
-  if (ri == MIJ_RESTART_AUTO) ri = choose_restart_interval(g.mcux, g.bpm);
-  if (ri < 1 || ri > 65535) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "restart_interval must be 1..65535 MCUs (or MIJ_RESTART_AUTO)"); }
-  g.ri = ri;
-  int row0 = p->strip_mcu_row0, rows = p->strip_mcu_rows;
-  if (rows == 0) { row0 = 0; rows = g.mcuy; }
-  if (row0 < 0 || rows < 0 || row0 + rows > g.mcuy) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip outside the image"); }
-  g.mcu_first = (long long)row0 * g.mcux;
-  g.mcu_count = (long long)rows * g.mcux;
-  if (g.mcu_first % ri) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not start on a restart-interval boundary"); }
-  g.last_strip = (row0 + rows == g.mcuy);
-  if (!g.last_strip && (g.mcu_count % ri)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not end on a restart-interval boundary"); }
-  g.y_origin = row0 * 8 * vs;
-  geom_finish(g);
-  if (p->progressive && (row0 != 0 || rows != g.mcuy)) { delete e; return fail(nullptr, MIJ_ERR_INVALID_ARG, "progressive output is for whole images (no strips)"); }
+  const int ri = g.ri, hs = g.hs, vs = g.vs;
   e->nseg = (g.mcu_count + ri - 1) / ri;
   e->coef_count = (size_t)g.mcu_count * g.bpm * 64;
   e->slot_bytes = (((size_t)ri * g.bpm * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
@@ -250,7 +273,7 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
     CRCHK(hipMalloc(&e->d_chunk_base, nch * sizeof(unsigned long long))); }
   CRCHK(hipMalloc(&e->d_ovf, sizeof(uint32_t)));
   CRCHK(hipMemset(e->d_ovf, 0, sizeof(uint32_t)));
-  CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity));
+  CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity + 64));
   CRCHK(hipMalloc(&e->d_res, sizeof(DeviceResult)));
   CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
   if (p->progressive) {
@@ -474,7 +497,7 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
     // sizes are known before anything is placed, so simply make room
     const size_t need = off + 65536;
     uint8_t *nb = nullptr;
-    if (hipMalloc(&nb, HDR_AREA + need) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
+    if (hipMalloc(&nb, HDR_AREA + need + 64) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
     (void)hipFree(e->d_out);
     e->d_out = nb; e->capacity = need;
   }
@@ -531,6 +554,134 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   return MIJ_OK;
 }
 
+// ---- strip sharding without host round trips ------------------------------------
+// The one-GPU entry points above learn the strip size on the host (mij_encode_result) -- fine for one GPU, a pipeline
+// stall per image when N ranks must agree on offsets. These three keep sizes and offsets on the device:
+//   mij_encode_entropy_sizes : tables + entropy coding + size scan; the strip's byte count lands in *d_size_slot
+//   [caller all-gathers the slots of all ranks into d_sizes[world], on the device]
+//   mij_encode_place         : compaction (K6) into this handle's own buffer; ranks > 0 then PUT the strip into rank 0's
+//                              buffer (peer-mapped, see mij_ipc_*) at sum(d_sizes[0..rank)).
+// The fast entropy coder leaves intervals with an oversized block to the roomy instantiation; here that one is always
+// enqueued behind it (it exits at once for every other interval) so that no host decision sits in the pipeline.
+int mij_encode_entropy_sizes(mij_encoder *e, uint64_t *d_size_slot, void *stream) {
+  if (!e || !d_size_slot) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_entropy_sizes called before mij_encode_transform");
+  if (e->p.progressive) return fail(e, MIJ_ERR_INVALID_ARG, "progressive output is not sharded");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  e->last_stream = s;
+  const Geom &g = e->g;
+  if (e->p.optimized_huffman || !e->static_tables_ready) {
+    int rc = run_tail(e, s, true);
+    if (rc) return rc;
+    e->static_tables_ready = true;
+  }
+  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
+  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
+  HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s,
+                        reinterpret_cast<unsigned long long *>(d_size_slot)));
+  e->timed_run = false;
+  return MIJ_OK;
+}
+
+int mij_encode_place(mij_encoder *e, uint8_t *d_file_scan, size_t file_scan_capacity, const uint64_t *d_sizes, int rank, int world,
+                     void *stream) {
+  if (!e || !d_sizes || rank < 0 || rank >= world) return fail(e, MIJ_ERR_INVALID_ARG, "bad argument");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t *own_scan = e->d_out + HDR_AREA;
+  HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, own_scan, e->capacity,
+                           e->d_res, s));
+  if (rank > 0) {
+    if (!d_file_scan) return fail(e, MIJ_ERR_INVALID_ARG, "ranks > 0 need rank 0's scan area (mij_ipc_open)");
+    HIPCHK(e, launch_put(own_scan, reinterpret_cast<const unsigned long long *>(d_sizes), rank, world, d_file_scan, file_scan_capacity,
+                         e->capacity, e->d_res, s));
+  } else if (d_file_scan && d_file_scan != own_scan) {
+    return fail(e, MIJ_ERR_INVALID_ARG, "rank 0 assembles the file in its own buffer");
+  }
+  HIPCHK(e, hipEventRecord(e->ev_done, s));
+  e->last_stream = s;
+  e->issued = true;
+  e->wait_event = true;
+  e->sharded_pending = true;
+  return MIJ_OK;
+}
+
+// Waits for the last mij_encode_place on this handle and reports the assembled file (rank 0: header + all strips, sizes
+// read from d_sizes; other ranks: their own strip). MIJ_ERR_OVERFLOW if a strip or the file did not fit its buffer.
+int mij_sharded_result(mij_encoder *e, const uint64_t *d_sizes, int rank, int world, mij_result *o) {
+  if (!e || !d_sizes || !o || world < 1 || world > 4096) return fail(e, MIJ_ERR_INVALID_ARG, "bad argument");
+  if (!e->sharded_pending) return fail(e, MIJ_ERR_NOT_READY, "no mij_encode_place has been issued on this handle");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  HIPCHK(e, hipEventSynchronize(e->ev_done));
+  std::vector<uint64_t> sz((size_t)world);
+  HIPCHK(e, hipMemcpy(sz.data(), d_sizes, sz.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost));
+  if (e->h_res->flags & 3u) return fail(e, MIJ_ERR_OVERFLOW, "a strip or the assembled file exceeds its output buffer (mij_encoder_reserve_output)");
+  if (e->h_res->scan_bytes > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "strip exceeds this handle's output buffer");
+  uint64_t total = 0;
+  for (int r = 0; r < world; r++) total += sz[(size_t)r];
+  if (rank == 0 && total > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "assembled file exceeds rank 0's output buffer (mij_encoder_reserve_output)");
+  const size_t hb = e->h_res->header_bytes;
+  o->d_buffer = e->d_out;
+  o->header_offset = HDR_AREA - hb;
+  o->header_bytes = hb;
+  o->scan_offset = HDR_AREA;
+  o->scan_bytes = rank == 0 ? (size_t)total : (size_t)sz[(size_t)rank];
+  o->file_bytes = hb + o->scan_bytes;
+  return MIJ_OK;
+}
+
+// Room for `scan_capacity` bytes of entropy-coded data in this handle's output buffer (rank 0 of a sharded encode holds the
+// whole file, not just its strip). Call before the first encode and before exporting the buffer.
+int mij_encoder_reserve_output(mij_encoder *e, size_t scan_capacity) {
+  if (!e) return MIJ_ERR_INVALID_ARG;
+  if (scan_capacity <= e->capacity) return MIJ_OK;
+  HIPCHK(e, hipSetDevice(e->p.device));
+  if (e->issued) HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  uint8_t *nb = nullptr;
+  if (hipMalloc(&nb, HDR_AREA + scan_capacity + 64) != hipSuccess) { (void)hipGetLastError(); return fail(e, MIJ_ERR_ALLOC, "cannot reserve the output buffer"); }
+  (void)hipFree(e->d_out);
+  e->d_out = nb; e->capacity = scan_capacity;
+  e->static_tables_ready = false;      // the header lives in this buffer
+  return MIJ_OK;
+}
+
+int mij_output_buffer(mij_encoder *e, void **d_buffer, size_t *scan_offset, size_t *scan_capacity) {
+  if (!e || !d_buffer) return MIJ_ERR_INVALID_ARG;
+  *d_buffer = e->d_out;
+  if (scan_offset) *scan_offset = HDR_AREA;
+  if (scan_capacity) *scan_capacity = e->capacity;
+  return MIJ_OK;
+}
+
+// Peer mapping of a device allocation (hipIpcGetMemHandle / hipIpcOpenMemHandle): how ranks > 0 reach rank 0's output buffer.
+// `handle64` is MIJ_IPC_HANDLE_BYTES of opaque data to ship between processes (e.g. in a broadcast).
+int mij_ipc_export(const void *d_ptr, void *handle64) {
+  if (!d_ptr || !handle64) return MIJ_ERR_INVALID_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) <= MIJ_IPC_HANDLE_BYTES, "handle size");
+  hipIpcMemHandle_t h;
+  hipError_t he = hipIpcGetMemHandle(&h, const_cast<void *>(d_ptr));
+  if (he != hipSuccess) return fail(nullptr, MIJ_ERR_HIP, "hipIpcGetMemHandle", he);
+  memset(handle64, 0, MIJ_IPC_HANDLE_BYTES);
+  memcpy(handle64, &h, sizeof h);
+  return MIJ_OK;
+}
+int mij_ipc_open(int device, const void *handle64, void **d_ptr) {
+  if (!handle64 || !d_ptr) return MIJ_ERR_INVALID_ARG;
+  *d_ptr = nullptr;
+  HIPCHK(nullptr, hipSetDevice(device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof h);
+  hipError_t he = hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (he != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, MIJ_ERR_HIP, "hipIpcOpenMemHandle", he); }
+  return MIJ_OK;
+}
+int mij_ipc_close(void *d_ptr) {
+  if (!d_ptr) return MIJ_OK;
+  return hipIpcCloseMemHandle(d_ptr) == hipSuccess ? MIJ_OK : MIJ_ERR_HIP;
+}
+
 int mij_encode_device(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *stream) {
   int rc = mij_encode_transform(e, d_src, pitch, plane_stride, fmt, stream);
   if (rc) return rc;
@@ -558,7 +709,7 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
     // Output larger than the preallocated buffer (very high quality on noise): grow it and redo header + compaction.
     const size_t need = (size_t)e->h_res->scan_bytes + 65536;
     uint8_t *nb = nullptr;
-    if (hipMalloc(&nb, HDR_AREA + need) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
+    if (hipMalloc(&nb, HDR_AREA + need + 64) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
     (void)hipFree(e->d_out);
     e->d_out = nb; e->capacity = need;
     hipStream_t s = e->last_stream;
@@ -738,6 +889,13 @@ int mij_debug_tables(mij_encoder *e, uint8_t *dst) {
   DeviceTables t;
   HIPCHK(e, hipMemcpy(&t, e->d_tab, sizeof(t), hipMemcpyDeviceToHost));
   for (int i = 0; i < 4; i++) { memcpy(dst + i * 273, t.bits[i], 17); memcpy(dst + i * 273 + 17, t.vals[i], 256); }
+  return MIJ_OK;
+}
+
+int mij_copy_bench_device(void *d_dst, const void *d_src, size_t bytes, void *stream) {
+  if (!d_dst || !d_src || (bytes & 15) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) return MIJ_ERR_INVALID_ARG;
+  hipError_t he = launch_copy16(d_dst, d_src, bytes, (hipStream_t)stream);
+  if (he != hipSuccess) return fail(nullptr, MIJ_ERR_HIP, "k_copy16 launch", he);
   return MIJ_OK;
 }
 

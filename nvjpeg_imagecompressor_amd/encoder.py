@@ -69,6 +69,29 @@ class Encoder:
     def entropy(self, stream=0):
         _lib.check(self._L.mij_encode_entropy(self._h, C.c_void_p(stream)), self._h, "mij_encode_entropy")
 
+    # -- strip sharding with sizes / offsets kept on the device (mi_jpeg.h "Strip sharding") ------------------------
+    def entropy_sizes(self, d_size_slot, stream=0):
+        _lib.check(self._L.mij_encode_entropy_sizes(self._h, C.c_void_p(d_size_slot), C.c_void_p(stream)), self._h,
+                   "mij_encode_entropy_sizes")
+
+    def place(self, d_file_scan, file_capacity, d_sizes, rank, world, stream=0):
+        _lib.check(self._L.mij_encode_place(self._h, C.c_void_p(d_file_scan), file_capacity, C.c_void_p(d_sizes), rank, world,
+                                            C.c_void_p(stream)), self._h, "mij_encode_place")
+
+    def sharded_result(self, d_sizes, rank, world):
+        r = _lib.Result()
+        _lib.check(self._L.mij_sharded_result(self._h, C.c_void_p(d_sizes), rank, world, C.byref(r)), self._h, "mij_sharded_result")
+        return {f[0]: getattr(r, f[0]) for f in r._fields_}
+
+    def reserve_output(self, scan_capacity):
+        _lib.check(self._L.mij_encoder_reserve_output(self._h, scan_capacity), self._h, "mij_encoder_reserve_output")
+
+    def output_buffer(self):
+        """(device pointer of the output buffer, offset of the scan area inside it, capacity of the scan area)."""
+        p, off, cap = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _lib.check(self._L.mij_output_buffer(self._h, C.byref(p), C.byref(off), C.byref(cap)), self._h)
+        return p.value, off.value, cap.value
+
     def set_histogram_buffer(self, d_ptr):
         _lib.check(self._L.mij_set_histogram_buffer(self._h, C.c_void_p(d_ptr)), self._h)
 
@@ -200,6 +223,38 @@ class Decoder:
         return float(ms.value)
 
 
+def geometry_query(width, height, quality=95, optimized_huffman=True, css=0, restart_interval=MIJ_RESTART_AUTO):
+    """Geometry of the WHOLE image from the parameters alone (mij_geometry_query: no device, nothing allocated)."""
+    L = _lib.load()
+    p = _lib.EncoderParams(width, height, quality, int(bool(optimized_huffman)), _css_value(css), restart_interval, 0, 0, 0, 0)
+    g = _lib.Geometry()
+    rc = L.mij_geometry_query(C.byref(p), C.byref(g))
+    if rc:
+        msg = L.mij_last_error(None)
+        raise MiJpegError("mij_geometry_query failed (rc=%d): %s" % (rc, msg.decode() if msg else "?"))
+    return {f[0]: getattr(g, f[0]) for f in g._fields_}
+
+
+def ipc_export(d_ptr):
+    """64 opaque bytes that let another process map the allocation containing `d_ptr` (hipIpcGetMemHandle)."""
+    L = _lib.load()
+    h = (C.c_uint8 * 64)()
+    _lib.check(L.mij_ipc_export(C.c_void_p(d_ptr), h), None, "mij_ipc_export")
+    return bytes(h)
+
+
+def ipc_open(device, handle):
+    L = _lib.load()
+    p = C.c_void_p()
+    buf = (C.c_uint8 * 64).from_buffer_copy(handle)
+    _lib.check(L.mij_ipc_open(device, buf, C.byref(p)), None, "mij_ipc_open")
+    return p.value
+
+
+def ipc_close(d_ptr):
+    _lib.load().mij_ipc_close(C.c_void_p(d_ptr))
+
+
 def residual_device(d_a, d_b, d_out, nbytes, mode, stream=0):
     """mode -1: out = clip(a - b + 128); mode +1: out = clip(a + b - 128) (difference-map compression)."""
     L = _lib.load()
@@ -227,6 +282,12 @@ def pinned_empty(shape, dtype=np.uint8):
     buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
     buf._mij_owner = _PinnedBlock(L, ptr)    # freed when the last array over `buf` is gone
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def copy_bench_device(d_dst, d_src, nbytes, stream=0):
+    """Streaming-copy yardstick kernel (bench only): 16 B per lane, grid-stride."""
+    L = _lib.load()
+    _lib.check(L.mij_copy_bench_device(C.c_void_p(d_dst), C.c_void_p(d_src), nbytes, C.c_void_p(stream)), None, "mij_copy_bench_device")
 
 
 def synth_image_device(d_ptr, width, y0, rows, pitch, bgr=False, stream=0):

@@ -7,26 +7,43 @@ restart-interval boundary, so that the only data exchanged between ranks is
 
   1. ONE all-reduce (sum) of the 4 x 257 uint32 symbol statistics  -- only with optimised Huffman tables, because a
      single-scan baseline file can carry only one set of tables;
-  2. ONE all-gather of the strips' byte counts (8 bytes per rank);
-  3. the gather of the finished strip bitstreams to rank 0 (point-to-point sends: xGMI links run in parallel).
+  2. ONE all-gather of the strips' byte counts (8 bytes per rank), device tensor to device tensor;
+  3. the gather of the finished strip bitstreams to rank 0.
 
-Everything else is local arithmetic. This module only sequences those steps; the JPEG work is done by a "strip
-encoder" object (the HIP one below; the CPU tests plug in the oracle) with
+Everything else is local arithmetic. Two orchestrations of those steps:
 
-    transform(stream)  -> 1-D int32 tensor of 4*257 statistics (device resident for the HIP encoder)
-    entropy(stream)    -> (header, scan): 1-D uint8 tensors; `header` is the SOI..SOS prefix (same on every rank),
-                          `scan` this strip's entropy-coded bytes including its trailing RSTn or, last strip, EOI.
+* `DevicePipeline` (the measured path): sizes and offsets never visit the host. Rank 0 assembles the file in its own
+  output buffer; the other ranks map that buffer (hipIpc*) and PUT their strip into it at the offset a kernel computes
+  from the all-gathered sizes, over their own xGMI link. DEPTH (3) images are in flight per rank, each on its own
+  stream and its own communicator, so that one image's collectives and its put run under the other images' kernels.
+  Nothing in a steady-state step waits on the host.
+* `StripPipeline` / `encode_step` (fallback when the peer mapping is unavailable, and the simple one-image form): sizes
+  come to the host, strips travel as RCCL send/recv.
+
+This module only sequences those steps; the JPEG work is done by a "strip encoder" object (the HIP one below; the CPU
+tests plug in the oracle) with
+
+    transform(stream)          -> 1-D int32 tensor of 4*257 statistics (device resident for the HIP encoder)
+    entropy(stream)            -> (header, scan) uint8 tensors                      [host-synchronised path]
+    entropy_sizes(slot, stream)   writes the strip's byte count into the 1-element int64 tensor `slot`
+    place(target, sizes, rank, world, stream)   strip -> the assembled file at offset sum(sizes[:rank])
+    file(target, sizes, rank, world)            rank 0: the assembled file (waits for this handle's work)
 """
-import ctypes as C
+from .encoder import Encoder, geometry_query, ipc_close, ipc_export, ipc_open
 
-from .encoder import Encoder
+DEPTH = 3          # images in flight per rank in DevicePipeline
 
 
 def partition_mcu_rows(mcu_rows, world, rank, rows_per_unit=1):
     """MCU rows [r0, r1) of rank `rank`: contiguous, as even as possible, in units of `rows_per_unit` MCU rows (the number
-    of MCU rows a restart interval spans when it is longer than one row; 1 when the interval divides the row)."""
+    of MCU rows a restart interval spans when it is longer than one row; 1 when the interval divides the row). With fewer
+    units than ranks the FIRST ranks get one unit each and the rest are empty (r0 == r1): rank 0, which assembles the
+    file and writes its header, always owns the first strip."""
     units = (mcu_rows + rows_per_unit - 1) // rows_per_unit
-    u0, u1 = rank * units // world, (rank + 1) * units // world
+    if units >= world:
+        u0, u1 = rank * units // world, (rank + 1) * units // world
+    else:
+        u0, u1 = min(rank, units), min(rank + 1, units)
     return min(u0 * rows_per_unit, mcu_rows), min(u1 * rows_per_unit, mcu_rows)
 
 
@@ -52,20 +69,30 @@ class HipStripEncoder:
         self.enc.transform(self.d_img.data_ptr(), self.pitch, self.fmt, 0, stream)
         return self.d_hist
 
+    # ---- device-side protocol (DevicePipeline) ----
+    def entropy_sizes(self, slot, stream=0):
+        self.enc.entropy_sizes(slot.data_ptr(), stream)
+
+    def place(self, target, sizes, rank, world, stream=0):
+        ptr, cap = target if rank else (0, 0)       # rank 0 assembles in its own buffer
+        self.enc.place(ptr, cap, sizes.data_ptr(), rank, world, stream)
+
+    def file(self, target, sizes, rank, world):
+        r = self.enc.sharded_result(sizes.data_ptr(), rank, world)
+        self.last_result = r
+        return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device) if rank == 0 else None
+
+    # ---- host-synchronised protocol (encode_step / StripPipeline) ----
     def entropy(self, stream=0):
         self.enc.entropy(stream)
-        r = self.enc.result()    # waits for this strip; sizes are now known on the host
-        self.last_result = r
-        dev = self.d_img.device
-        return (self._view(r["d_buffer"] + r["header_offset"], r["header_bytes"], dev),
-                self._view(r["d_buffer"] + r["scan_offset"], r["scan_bytes"], dev))
+        return self.collect_strip()
 
     def issue_entropy(self, stream=0):
-        """Enqueue the entropy stage and return at once (pipelined multi-rank step); `collect_strip` waits for it."""
+        """Enqueue the entropy stage and return at once; `collect_strip` waits for it."""
         self.enc.entropy(stream)
 
     def collect_strip(self):
-        r = self.enc.result()    # waits for this strip only (per-encode event)
+        r = self.enc.result()    # waits for this strip only (per-encode event); sizes are now known on the host
         self.last_result = r
         dev = self.d_img.device
         return (self._view(r["d_buffer"] + r["header_offset"], r["header_bytes"], dev),
@@ -116,17 +143,177 @@ def device_bytes(torch, ptr, nbytes, device):
     return torch.as_tensor(h, device=device)
 
 
+# =====================================================================================================================
+# Device-side pipeline: no host round trip in a step
+# =====================================================================================================================
+class DevicePipeline:
+    """DEPTH images in flight per rank; per image and rank, enqueued without a single host wait:
+
+        slot k = i % DEPTH, on stream S_k and communicator G_k:
+          transform(i) -> all_reduce(statistics) -> entropy_sizes(i) -> all_gather(sizes) -> place(i)
+
+    `place` compacts the strip locally and, on ranks > 0, puts it into rank 0's buffer of slot k at the offset a kernel
+    derives from the gathered sizes. One communicator per slot: collectives of different images then do not queue behind
+    each other (on one communicator the next image's all-reduce would wait for this image's all-gather, which waits for
+    this image's entropy coder). Every rank issues the same collectives in the same order.
+
+    Hazards, all resolved by stream order: a handle (coefficients, scratch, output buffer) is reused by image i + DEPTH on
+    the same stream; a peer's put of image i + DEPTH into rank 0's buffer k can only start after the all-gather of that
+    image, i.e. after rank 0 has enqueued everything of image i on S_k. The file of image i is complete on rank 0 once a
+    LATER collective of slot k has completed there (each peer enqueues it behind its put) -- `collect` issues one.
+
+    `strips` holds DEPTH strip encoders, or None on a rank that owns no strip (more ranks than restart-aligned strips):
+    such a rank contributes zero statistics and a zero size. `targets[k]` is what `place` / `file` take for slot k
+    (`open_file_targets` for the HIP encoder). An empty rank is never rank 0 (partition_mcu_rows).
+    """
+
+    def __init__(self, torch, dist, strips, targets, optimize, device=None, use_streams=None):
+        self.torch, self.dist, self.strips, self.targets, self.optimize = torch, dist, strips, targets, optimize
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.depth = len(targets)
+        if device is None:
+            device = next((s.d_img.device for s in (strips or []) if s is not None and getattr(s, "d_img", None) is not None), torch.device("cpu"))
+        self.device = device
+        cuda = device.type == "cuda"
+        self.use_streams = cuda if use_streams is None else use_streams
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)] if self.use_streams else [None] * self.depth
+        if self.use_streams:
+            for s in self.streams:
+                s.wait_stream(torch.cuda.current_stream(device))      # the image was produced on the current stream
+        self.groups = [dist.new_group() for _ in range(self.depth)]   # same order on every rank
+        self.mine = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.depth)]
+        self.sizes = [torch.zeros(self.world, dtype=torch.int64, device=device) for _ in range(self.depth)]
+        self.zero_hist = [torch.zeros(4 * 257, dtype=torch.int32, device=device) for _ in range(self.depth)]
+        self.done = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(self.depth)]
+        self.i = 0
+        self.pending = []         # slots whose image has been issued and not yet collected, oldest first
+
+    def _ctx(self, k):
+        import contextlib
+        return self.torch.cuda.stream(self.streams[k]) if self.use_streams else contextlib.nullcontext()
+
+    def _all_gather(self, out, inp, group):
+        try:
+            self.dist.all_gather_into_tensor(out, inp, group=group)
+        except (RuntimeError, AttributeError):       # a backend without the flat form
+            parts = [self.torch.empty_like(inp) for _ in range(self.world)]
+            self.dist.all_gather(parts, inp, group=group)
+            out.copy_(self.torch.cat(parts))
+
+    def step(self):
+        """Issue the next image on slot i % DEPTH and return at once (no host wait, no collective beyond the image's own
+        two). An older image still uncollected in that slot is overwritten: its file stays valid only until the peers' puts of
+        the new image start, so callers that want EVERY file call `collect` before the slot comes round again."""
+        k = self.i % self.depth
+        self.pending = [q for q in self.pending if q != k]
+        self.i += 1
+        st = self.strips[k] if self.strips else None
+        sh = self.streams[k].cuda_stream if self.use_streams else 0
+        with self._ctx(k):
+            hist = st.transform(sh) if st is not None else self.zero_hist[k].zero_()
+            if self.optimize:
+                self.dist.all_reduce(hist, group=self.groups[k])
+            if st is not None:
+                st.entropy_sizes(self.mine[k], sh)
+            self._all_gather(self.sizes[k], self.mine[k], self.groups[k])
+            if st is not None:
+                st.place(self.targets[k], self.sizes[k], self.rank, self.world, sh)
+        self.pending.append(k)
+        return k
+
+    def collect(self, want_file=True):
+        """Complete the OLDEST pending image: one small collective behind every rank's put, a wait for this rank's stream,
+        then (rank 0, if wanted) the assembled file. Every rank must call this the same number of times, in the same order
+        relative to `step`. Not part of a steady-state step: the bench only flushes at the end of the timed region."""
+        if not self.pending:
+            return None
+        k = self.pending.pop(0)
+        with self._ctx(k):
+            self.dist.all_reduce(self.done[k], group=self.groups[k])
+        if self.use_streams:
+            self.streams[k].synchronize()
+        st = self.strips[k] if self.strips else None
+        if st is None:
+            return None
+        out = st.file(self.targets[k], self.sizes[k], self.rank, self.world)   # also checks this handle's status
+        return out if (want_file and self.rank == 0) else None
+
+    def flush(self):
+        """Complete everything in flight; returns (rank 0) the file of the LAST image issued."""
+        out = None
+        while self.pending:
+            out = self.collect(want_file=len(self.pending) == 1)
+        if self.use_streams:
+            for s in self.streams:
+                self.torch.cuda.current_stream(self.device).wait_stream(s)
+        return out
+
+
+def full_scan_capacity(geometry):
+    """Bytes to reserve for the entropy-coded data of the WHOLE image (what one handle reserves for its strip, scaled up):
+    two bytes per coefficient cover every photographic setting; noise at q100 can exceed it (MIJ_ERR_OVERFLOW then)."""
+    return geometry["mcus_per_row"] * geometry["mcu_rows"] * geometry["blocks_per_mcu"] * 64 + 65536
+
+
+def open_file_targets(torch, dist, strips, rank, world, device_index, whole_geometry):
+    """Peer mapping of rank 0's DEPTH output buffers on every other rank (mij_ipc_export / mij_ipc_open). Returns the list
+    of per-slot targets for DevicePipeline, or None when ANY rank could not map (then every rank takes the send/recv
+    fallback). Rank 0 first reserves room for the whole file in each of its handles."""
+    cap = full_scan_capacity(whole_geometry)
+    payload, ok, targets = [None], True, None
+    if rank == 0:
+        try:
+            handles = []
+            for st in strips:
+                st.enc.reserve_output(cap)
+                base, off, c = st.enc.output_buffer()
+                handles.append((ipc_export(base), off, c))
+            payload = [handles]
+        except Exception as e:       # noqa: BLE001 -- any failure means "no peer mapping": all ranks fall back together
+            payload, ok = [("error", str(e))], False
+    dist.broadcast_object_list(payload, src=0)
+    handles = payload[0]
+    if isinstance(handles, tuple) and handles and handles[0] == "error":
+        ok = False
+    elif rank == 0:
+        targets = [(0, 0)] * len(handles)
+    else:
+        try:
+            targets = []
+            for h, off, c in handles:
+                targets.append((ipc_open(device_index, h) + off, c))
+        except Exception:            # noqa: BLE001
+            ok = False
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(ok))
+    if not all(oks):
+        if targets and rank:
+            for p, _ in targets:
+                try:
+                    ipc_close(p)
+                except Exception:    # noqa: BLE001
+                    pass
+        return None
+    return targets
+
+
+# =====================================================================================================================
+# Host-synchronised forms (fallback / one image at a time)
+# =====================================================================================================================
 def encode_step(torch, dist, strip_encoder, optimize, out_cache, stream=0):
-    """One whole-image encode across all ranks of the default process group. Returns, on rank 0, a uint8 tensor holding the
-    complete JFIF file (a view into `out_cache["buf"]`, reused across calls); None on the other ranks."""
+    """One whole-image encode across all ranks of the default process group, one image at a time. Returns, on rank 0, a
+    uint8 tensor holding the complete JFIF file (a view into `out_cache["buf"]`, reused across calls); None on the other
+    ranks. `strip_encoder` may be None on a rank that owns no strip."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    hist = strip_encoder.transform(stream)
+    hist = strip_encoder.transform(stream) if strip_encoder is not None else torch.zeros(4 * 257, dtype=torch.int32, device=out_cache.get("device", "cpu"))
     if world > 1 and optimize:
         dist.all_reduce(hist)                      # the only collective on the data path before entropy coding
     if world == 1 and hasattr(strip_encoder, "encode_whole"):
         return strip_encoder.encode_whole(stream)
-    header, scan = strip_encoder.entropy(stream)
+    if strip_encoder is not None:
+        header, scan = strip_encoder.entropy(stream)
+    else:
+        header = scan = torch.zeros(0, dtype=torch.uint8, device=hist.device)
     if world == 1:
         n = header.numel() + scan.numel()
         buf = _buffer(torch, out_cache, n, scan.device)
@@ -137,9 +324,9 @@ def encode_step(torch, dist, strip_encoder, optimize, out_cache, stream=0):
 
 
 class StripPipeline:
-    """Multi-rank encode with TWO images in flight per rank, so that the gather of image i-1 to rank 0 (the longest leg:
-    (N-1)/N of the file crosses rank 0's xGMI links) and the host round trips for its sizes run while image i's kernels
-    do. Every rank executes the same sequence of collectives, in the same order:
+    """Host-synchronised multi-rank encode with TWO images in flight per rank (the fallback when rank 0's buffers cannot be
+    peer-mapped): the gather of image i-1 to rank 0 as RCCL send/recv and the host round trips for its sizes run while
+    image i's kernels do. Every rank executes the same sequence of collectives, in the same order:
 
         step i:   transform(i) -> all_reduce(statistics i) -> entropy(i)           [enqueued, no host wait]
                   sizes(i-1): all_gather -> host;  gather(i-1): point-to-point      [on a side stream]
@@ -191,7 +378,7 @@ class StripPipeline:
 
 
 def _gather_to_rank0(torch, dist, header, scan, cache):
-    """all_gather of the strip sizes, then the strips travel to rank 0 point-to-point (same protocol as encode_step)."""
+    """all_gather of the strip sizes, then the strips travel to rank 0 point-to-point."""
     world, rank = dist.get_world_size(), dist.get_rank()
     mine = torch.tensor([scan.numel()], dtype=torch.int64, device=scan.device)
     sizes = torch.zeros(world, dtype=torch.int64, device=scan.device)
@@ -227,19 +414,24 @@ def _buffer(torch, cache, n, device):
     return buf
 
 
-def make_hip_strip_encoder(torch, width, height, quality, optimize, css, rank, world, device_index, fmt="bgr",
-                           restart_interval=-1, progressive=False):
-    """Creates this rank's Encoder for its strip plus the geometry needed to fill the strip with pixels."""
-    probe = Encoder(width, height, quality, optimize, css, restart_interval, device_index, 0, 1)
-    g0 = probe.geometry
-    probe.close()
+def strip_rows(width, height, quality, optimize, css, rank, world, restart_interval=-1):
+    """(whole-image geometry, first MCU row, one-past-last MCU row) of `rank`: pure arithmetic (mij_geometry_query), no
+    device and no communication. r0 == r1: this rank owns no strip."""
+    g0 = geometry_query(width, height, quality, optimize, css, restart_interval)
     unit = rows_per_restart_unit(g0["mcus_per_row"], g0["restart_interval"])
     r0, r1 = partition_mcu_rows(g0["mcu_rows"], world, rank, unit)
-    if r1 <= r0:
-        raise ValueError("more ranks than restart-aligned strips: rank %d would be empty" % rank)
+    return g0, r0, r1
+
+
+def make_hip_strip_encoder(torch, width, height, quality, optimize, css, rank, world, device_index, fmt="bgr",
+                           restart_interval=-1, progressive=False):
+    """This rank's Encoder for its strip (its `geometry` tells which pixel rows to fill), or None if the rank owns no strip
+    (more ranks than restart-aligned strips)."""
+    g0, r0, r1 = strip_rows(width, height, quality, optimize, css, rank, world, restart_interval)
     if progressive:
         if world != 1:
             raise ValueError("progressive output is not sharded: every scan spans the whole image")
         return Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, progressive=True)
-    enc = Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, r0, r1 - r0)
-    return enc
+    if r1 <= r0:
+        return None
+    return Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, r0, r1 - r0)

@@ -9,6 +9,9 @@
  *   ijg_harness coef in.jpg out.bin      (int16; per component: blocks in raster order, natural coefficient order;
  *                                         preceded by a header of int32: ncomp, then per comp wib, hib, hs, vs)
  *   ijg_harness dec  in.jpg out.raw      (RGB8 interleaved, library defaults)
+ *   ijg_harness bench in.raw W H quality hs vs optimize restart_mcus reps
+ *                                        (CPU baseline for 4:4:0 / 4:1:1, bench.py: encodes to memory `reps` times, prints
+ *                                         "<best seconds> <bytes>"; file reading is outside the timed region)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,6 +62,52 @@ static int do_enc(int argc, char **argv) {
   jpeg_finish_compress(&c);
   jpeg_destroy_compress(&c);
   fclose(fo); free(raw);
+  return 0;
+}
+
+#include <time.h>
+static int do_bench(int argc, char **argv) {
+  if (argc != 11) return 1;
+  size_t n; unsigned char *raw = slurp(argv[2], &n);
+  int W = atoi(argv[3]), H = atoi(argv[4]);
+  int quality = atoi(argv[5]), hs = atoi(argv[6]), vs = atoi(argv[7]), opt = atoi(argv[8]), rst = atoi(argv[9]), reps = atoi(argv[10]);
+  if (n < (size_t)W * H * 3) { fprintf(stderr, "short input\n"); return 2; }
+  double best = 1e30; unsigned long bytes = 0;
+  for (int r = 0; r < reps; r++) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    struct jpeg_compress_struct c; struct jpeg_error_mgr e;
+    c.err = jpeg_std_error(&e);
+    jpeg_create_compress(&c);
+    unsigned char *out = NULL; unsigned long outn = 0;
+    jpeg_mem_dest(&c, &out, &outn);
+    c.image_width = W; c.image_height = H; c.input_components = 3; c.in_color_space = JCS_RGB;
+    jpeg_set_defaults(&c);
+    jpeg_set_quality(&c, quality, TRUE);
+    c.comp_info[0].h_samp_factor = hs; c.comp_info[0].v_samp_factor = vs;
+    c.comp_info[1].h_samp_factor = 1; c.comp_info[1].v_samp_factor = 1;
+    c.comp_info[2].h_samp_factor = 1; c.comp_info[2].v_samp_factor = 1;
+    c.optimize_coding = opt ? TRUE : FALSE;
+    c.restart_interval = rst;
+    c.dct_method = JDCT_ISLOW;
+#if JPEG_LIB_VERSION >= 70
+    c.do_fancy_downsampling = FALSE;
+#endif
+    jpeg_start_compress(&c, TRUE);
+    while (c.next_scanline < c.image_height) {
+      JSAMPROW row = raw + (size_t)c.next_scanline * W * 3;
+      jpeg_write_scanlines(&c, &row, 1);
+    }
+    jpeg_finish_compress(&c);
+    jpeg_destroy_compress(&c);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (dt < best) best = dt;
+    bytes = outn;
+    free(out);
+  }
+  printf("%.6f %lu\n", best, bytes);
+  free(raw);
   return 0;
 }
 
@@ -126,6 +175,7 @@ int main(int argc, char **argv) {
     if (!strcmp(argv[1], "enc")) rc = do_enc(argc, argv);
     else if (!strcmp(argv[1], "coef")) rc = do_coef(argc, argv);
     else if (!strcmp(argv[1], "dec")) rc = do_dec(argc, argv);
+    else if (!strcmp(argv[1], "bench")) rc = do_bench(argc, argv);
   }
   if (rc == 1) fprintf(stderr, "usage: see header comment of ijg_harness.c\n");
   return rc;

@@ -1,5 +1,9 @@
-"""Strip sharding with the HIP strip encoder: two ranks share the one GPU of the test box (gloo carries the collectives;
-RCCL refuses two ranks on one device), each encodes its strip, rank 0 gathers. Must equal the oracle's one-shot file."""
+"""Strip sharding with the HIP strip encoder: N ranks share the one GPU of the test box (gloo carries the collectives;
+RCCL refuses two ranks on one device), each encodes its strip. Two gathers: the device-side pipeline (sizes all-gathered
+device to device, strips PUT into rank 0's buffer through hipIpc mappings -- between processes on one GPU here, between
+GPUs over xGMI on the node) and the host-synchronised send/recv form. Must equal the oracle's one-shot file.
+(At most 6 processes may use the test box's GPU at once: 5 ranks next to the test process is the largest world here; the
+8-rank orchestration is covered on CPU, tests/test_sharded_cpu.py.)"""
 import os
 import socket
 import sys
@@ -38,6 +42,73 @@ def _worker(rank, world, port, W, H, css, optimize, out_path):
     dist.destroy_process_group()
 
 
+def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path):
+    """sharded.DevicePipeline on real HIP handles: DEPTH images in flight, peer-mapped rank-0 buffers, k_put."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nvjpeg_imagecompressor_amd as mij
+    from nvjpeg_imagecompressor_amd import sharded
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    whole, r0, r1 = sharded.strip_rows(W, H, 95, optimize, css, rank, world, ri)
+    encs = [sharded.make_hip_strip_encoder(torch, W, H, 95, optimize, css, rank, world, 0, "rgb", restart_interval=ri) for _ in range(sharded.DEPTH)]
+    strips = None
+    imgs = []
+    if encs[0] is not None:
+        g = encs[0].geometry
+        for i in range(nimg):       # image i = the synthetic image shifted down by 8 i rows (so that the strips differ per image)
+            t = torch.empty((g["strip_rows"], W, 3), dtype=torch.uint8, device=dev)
+            mij.synth_image_device(t.data_ptr(), W, g["strip_y0"] + 8 * i, g["strip_rows"], W * 3, bgr=False)
+            imgs.append(t)
+        torch.cuda.synchronize()
+        strips = [sharded.HipStripEncoder(torch, e, imgs[0], "rgb") for e in encs]
+    else:
+        assert r0 == r1 and rank > 0
+    targets = sharded.open_file_targets(torch, dist, strips, rank, world, 0, whole)
+    assert targets is not None, "hipIpc mapping of rank 0's buffers failed"
+    pipe = sharded.DevicePipeline(torch, dist, strips, targets, optimize, device=dev)
+    outs = []
+    for i in range(nimg):
+        if strips is not None:
+            strips[i % sharded.DEPTH].d_img = imgs[i]
+        pipe.step()
+        if collect_each:
+            o = pipe.collect()
+            outs.append(None if o is None else o.cpu().numpy().tobytes())
+    last = pipe.flush()
+    if not collect_each:
+        outs = [None] * (nimg - 1) + [None if last is None else last.cpu().numpy().tobytes()]
+    if rank == 0:
+        for i, o in enumerate(outs):
+            if o is not None:
+                open(out_path + ".%d" % i, "wb").write(o)
+        open(out_path + ".ri", "w").write(str(whole["restart_interval"]))
+    dist.barrier()
+    for e in encs:
+        if e is not None:
+            e.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,css,optimize,ri,H,collect_each", [
+    (2, 1, True, -1, 1000, True), (3, 2, True, -1, 1000, True), (5, 1, True, -1, 2504, True), (3, 0, False, -1, 1000, True),
+    (3, 1, True, 260, 1000, True),     # interval = two MCU rows (130 MCUs per row): strips cut in units of two rows
+    (5, 1, True, 3900, 480, True),     # one restart-aligned strip per 30 MCU rows: 2 units for 5 ranks, three of them own nothing
+    (3, 1, True, -1, 1000, False), (5, 2, True, -1, 2504, False),
+])
+def test_device_pipeline_put_gather(oracle, tmp_path, world, css, optimize, ri, H, collect_each):
+    import numpy as np
+    W, nimg = 2080, 5
+    out = str(tmp_path / "dev.jpg")
+    mp.spawn(_device_worker, args=(world, _free_port(), W, H, css, optimize, ri, nimg, collect_each, out), nprocs=world, join=True)
+    dri = int(open(out + ".ri").read())
+    full = oracle.synth_rgb(W, H + 8 * nimg)
+    for i in (range(nimg) if collect_each else [nimg - 1]):
+        want = oracle.encode(np.ascontiguousarray(full[8 * i:8 * i + H]), 95, css, optimize, dri)
+        got = open(out + ".%d" % i, "rb").read()
+        assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want), i
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -70,25 +141,27 @@ def test_hip_strips_five_ranks_uneven(oracle, tmp_path):
     assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want)
 
 
-@pytest.mark.parametrize("pipeline", [True, False])
+@pytest.mark.parametrize("pipeline", ["put", "sendrecv", None])
 def test_bench_multi_rank_rehearsal(tmp_path, pipeline):
     """bench.py's N > 1 path end to end (launcher, strips, collectives, gather, the JSON line), rehearsed with three ranks
-    on the one GPU over gloo: the file must be the single-GPU file. Both forms of the step: two images in flight per
-    rank (sharded.StripPipeline, the default) and one at a time (sharded.encode_step)."""
+    on the one GPU over gloo: the file must be the single-GPU file. All three forms of the step: three images in flight
+    with the put gather (sharded.DevicePipeline, the default), two in flight with send/recv (sharded.StripPipeline, the
+    fallback) and one at a time (sharded.encode_step)."""
     import json
     import subprocess
     env = dict(os.environ, MIJ_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    if not pipeline:
+    if pipeline is None:
         env["MIJ_BENCH_NO_PIPELINE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
            "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1",
-           "--no-cpu-baseline", "--height", "4000"]
+           "--no-cpu-baseline", "--height", "4000"] + (["--gather", pipeline] if pipeline else [])
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 3 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == (2 if pipeline else 1)
+    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == {"put": 3, "sendrecv": 2, None: 1}[pipeline]
+    assert d["config"]["gather"] == (pipeline or "sendrecv")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--no-psnr", "--height", "4000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-3000:]

@@ -1,7 +1,9 @@
-"""world_size-2 (and 3) gloo runs of the strip-sharding orchestration (nvjpeg_imagecompressor_amd/sharded.py) on CPU.
+"""world_size 2 / 3 / 5 / 8 gloo runs of the strip-sharding orchestration (nvjpeg_imagecompressor_amd/sharded.py) on CPU.
 The HIP strip encoder needs a GPU, so the per-strip JPEG work is done here by the oracle (test infrastructure); what
-is under test is the product's partitioning, the statistics all-reduce, the size all-gather and the bitstream gather:
-the N-rank file must equal the 1-rank file byte for byte."""
+is under test is the product's partitioning (incl. ranks that own no strip), the statistics all-reduce, the size
+all-gather and the gather of the strips -- both the device-side pipeline (DevicePipeline: DEPTH images in flight, strips
+PUT into rank 0's buffer at offsets derived from the gathered sizes; peer-mapped memory is played by shared-memory
+tensors) and the host-synchronised send/recv fallback: the N-rank file must equal the 1-rank file byte for byte."""
 import os
 import socket
 import sys
@@ -49,6 +51,21 @@ class OracleStripEncoder:
     def collect_strip(self):
         return self.entropy()
 
+    # ---- device-side protocol (sharded.DevicePipeline); `target` = rank 0's scan area, a shared-memory uint8 tensor ----
+    def entropy_sizes(self, slot, stream=0):
+        self._hdr, self._scan = self.entropy()
+        slot[0] = self._scan.numel()
+
+    def place(self, target, sizes, rank, world, stream=0):
+        off = int(sizes[:rank].sum())
+        assert int(sizes[rank]) == self._scan.numel()
+        target[off:off + self._scan.numel()] = self._scan
+
+    def file(self, target, sizes, rank, world):
+        if rank != 0:
+            return None
+        return torch.cat([self._hdr, target[:int(sizes.sum())]])
+
 
 def _pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, out_path):
     """StripPipeline: `nimg` different images through two alternating strip encoders; rank 0 saves every file."""
@@ -90,8 +107,9 @@ def _worker(rank, world, port, W, H, css, optimize, ri, q, out_path):
     r0, r1 = sharded.partition_mcu_rows(geo["mcuy"], world, rank, unit)
     mcu_h = 8 * geo["vs"]
     y0, y1 = r0 * mcu_h, min(r1 * mcu_h, H)
-    img = O.synth_rgb(W, H, y0, y1 - y0)
-    enc = OracleStripEncoder(O, img, W, H, q, css, optimize, ri, r0, r1, geo)
+    enc = None
+    if r1 > r0:      # a rank may own no strip (fewer restart-aligned strips than ranks): it still joins every collective
+        enc = OracleStripEncoder(O, O.synth_rgb(W, H, y0, y1 - y0), W, H, q, css, optimize, ri, r0, r1, geo)
     out = sharded.encode_step(torch, dist, enc, optimize, {})
     if rank == 0:
         open(out_path, "wb").write(out.numpy().tobytes())
@@ -99,6 +117,68 @@ def _worker(rank, world, port, W, H, css, optimize, ri, q, out_path):
         assert out is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, collect_each, targets, out_path):
+    """DevicePipeline: `nimg` different images; either every file is collected before its slot comes round again
+    (collect_each) or the loop runs like the bench -- issue only, one flush at the end, which yields the LAST file."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from nvjpeg_imagecompressor_amd import sharded
+    geo = O.geometry(W, H, css)
+    unit = sharded.rows_per_restart_unit(geo["mcux"], ri)
+    r0, r1 = sharded.partition_mcu_rows(geo["mcuy"], world, rank, unit)
+    mcu_h = 8 * geo["vs"]
+    y0, y1 = r0 * mcu_h, min(r1 * mcu_h, H)
+    depth = len(targets)
+    encs = [OracleStripEncoder(O, None, W, H, q, css, optimize, ri, r0, r1, geo) for _ in range(depth)] if r1 > r0 else None
+    assert rank != 0 or encs is not None              # rank 0 always owns the first strip
+    pipe = sharded.DevicePipeline(torch, dist, encs, targets, optimize, device=torch.device("cpu"))
+    outs = []
+    for i in range(nimg):
+        if encs is not None:
+            encs[i % depth].img = np.roll(O.synth_rgb(W, H), 7 * i, axis=1)[y0:y1].copy()    # image i
+        pipe.step()
+        if collect_each:
+            o = pipe.collect()
+            outs.append(None if o is None else o.clone())
+    last = pipe.flush()
+    if not collect_each:
+        outs = [None] * (nimg - 1) + [None if last is None else last.clone()]
+    if rank == 0:
+        for i, o in enumerate(outs):
+            if o is not None:
+                open(out_path + ".%d" % i, "wb").write(o.numpy().tobytes())
+    else:
+        assert all(o is None for o in outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _shared_targets(depth, nbytes):
+    return [torch.zeros(nbytes, dtype=torch.uint8).share_memory_() for _ in range(depth)]
+
+
+@pytest.mark.parametrize("world,css,optimize,ri,collect_each", [
+    (2, 1, True, 13, True), (3, 1, True, 13, True), (5, 2, True, 26, True), (8, 1, True, 13, True), (8, 0, False, 13, True),
+    (2, 1, True, 40, True),        # one restart-aligned strip only: rank 1 owns nothing (the case round 1 dropped)
+    (8, 1, True, 26, True),        # interval spans 2 MCU rows: 16 units over 8 ranks
+    (8, 2, True, 104, True),       # 13 MCUs per row, 16 rows, interval 104 = 8 rows: 2 units, six empty ranks
+    (3, 1, True, 13, False), (8, 1, True, 13, False),
+])
+def test_device_pipeline_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri, collect_each):
+    """DEPTH images in flight, sizes all-gathered device-to-device, strips put at offsets derived from them: every image must
+    come out as the 1-rank file (collect_each), and a bench-style loop (issue only, flush once) must end on the last one."""
+    from nvjpeg_imagecompressor_amd import sharded
+    W, H, q, nimg = 208, 250, 92, 7
+    out = str(tmp_path / "dev.jpg")
+    targets = _shared_targets(sharded.DEPTH, 3 * W * (H + 16))
+    mp.spawn(_device_pipeline_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, nimg, collect_each, targets, out),
+             nprocs=world, join=True)
+    for i in (range(nimg) if collect_each else [nimg - 1]):
+        want = oracle.encode(np.roll(oracle.synth_rgb(W, H), 7 * i, axis=1).copy(), q, css, optimize, ri)
+        assert open(out + ".%d" % i, "rb").read() == want, i
 
 
 def _free_port():
@@ -109,8 +189,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("css,optimize,ri", [(1, True, 13), (2, True, 26), (0, False, 13), (1, True, 26)])  # last: interval spans 2 MCU rows
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("css,optimize,ri", [(1, True, 13), (2, True, 26), (0, False, 13), (1, True, 26),   # (1, 26): interval spans 2 MCU rows
+                                             (1, True, 40)])                                                # one strip only: empty ranks
 def test_n_rank_file_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri):
     W, H, q = 208, 250, 92          # H is not a multiple of the MCU height: the last strip owns the bottom edge
     out = tmp_path / "sharded.jpg"
@@ -139,9 +220,12 @@ def test_partition_arithmetic():
             for unit in (1, 2, 5):
                 cuts = [sharded.partition_mcu_rows(rows, world, r, unit) for r in range(world)]
                 assert cuts[0][0] == 0 and cuts[-1][1] == rows
+                assert cuts[0][1] > 0                      # rank 0 (header, file assembly) always owns the first strip
                 for (a0, a1), (b0, b1) in zip(cuts[:-1], cuts[1:]):
                     assert a1 == b0 and a0 <= a1
-                assert all(c[0] % unit == 0 for c in cuts)
+                assert all(c[0] % unit == 0 for c in cuts if c[1] > c[0])
+                empty = [c[1] == c[0] for c in cuts]
+                assert empty == sorted(empty)              # empty ranks, if any, come last
     assert sharded.rows_per_restart_unit(520, 104) == 1
     assert sharded.rows_per_restart_unit(520, 1040) == 2
     assert sharded.rows_per_restart_unit(26, 40) == 20      # 40 MCUs and 26 per row meet again after 20 rows

@@ -48,6 +48,9 @@ struct mij_encoder {
   uint32_t *d_seg_bytes = nullptr, *d_seg_ff = nullptr;
   unsigned long long *d_seg_off = nullptr, *d_chunk_total = nullptr, *d_chunk_base = nullptr;
   uint32_t *d_ovf = nullptr;
+  unsigned long long *d_status = nullptr;   // fused entropy coder: look-back status words + ticket
+  uint32_t *d_redo = nullptr;               // set by the fused coder when its result is unusable
+  bool fuse = false, fused_run = false;
   uint8_t *d_out = nullptr;
   size_t capacity = 0;  // scan-data capacity (bytes after HDR_AREA)
   DeviceResult *d_res = nullptr, *h_res = nullptr;
@@ -158,7 +161,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   (void)hipSetDevice(e->p.device);
   if (e->last_stream || e->issued) (void)hipStreamSynchronize(e->last_stream);
   (void)hipFree(e->d_qt); (void)hipFree(e->d_tab); (void)hipFree(e->d_hist_own); (void)hipFree(e->d_coef); (void)hipFree(e->d_dc);
-  (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off); (void)hipFree(e->d_chunk_total); (void)hipFree(e->d_chunk_base); (void)hipFree(e->d_ovf);
+  (void)hipFree(e->d_scratch); (void)hipFree(e->d_seg_bytes); (void)hipFree(e->d_seg_ff); (void)hipFree(e->d_seg_off); (void)hipFree(e->d_chunk_total); (void)hipFree(e->d_chunk_base); (void)hipFree(e->d_ovf); (void)hipFree(e->d_status); (void)hipFree(e->d_redo);
   (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src); (void)hipFree(e->d_sec);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
@@ -273,6 +276,13 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
     CRCHK(hipMalloc(&e->d_chunk_base, nch * sizeof(unsigned long long))); }
   CRCHK(hipMalloc(&e->d_ovf, sizeof(uint32_t)));
   CRCHK(hipMemset(e->d_ovf, 0, sizeof(uint32_t)));
+  CRCHK(hipMalloc(&e->d_status, (seg_alloc + 1) * sizeof(unsigned long long)));
+  CRCHK(hipMalloc(&e->d_redo, sizeof(uint32_t)));
+  CRCHK(hipMemset(e->d_redo, 0, sizeof(uint32_t)));
+  // Opt-in experiment (MIJ_FUSE=1): K4 with the size scan and the stuffing + compaction folded in (decoupled look-back).
+  // Measured SLOWER than the three separate kernels (0.91 vs 0.59 + 0.01 + 0.10 ms): the placement work is a
+  // latency-bound chain per interval that K6 runs at 32 waves per CU and the fused kernel at 16, on top of the coder.
+  e->fuse = getenv("MIJ_FUSE") != nullptr;
   CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity + 64));
   CRCHK(hipMalloc(&e->d_res, sizeof(DeviceResult)));
   CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
@@ -540,13 +550,21 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
     e->static_tables_ready = true;
   }
   if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
-  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
-  HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
-  HIPCHK(e, launch_compact(g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
-                           e->capacity, e->d_res, s));
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[6], s));
+  e->fused_run = e->fuse;
+  if (e->fuse) {
+    // K4 with the size scan and the stuffing + compaction folded in (k_encode<1, true>): stage times [4], [5] read 0
+    HIPCHK(e, launch_encode_fused(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, e->d_status,
+                                  e->d_redo, e->d_out + HDR_AREA, e->capacity, e->d_res, nullptr, s));
+    if (e->timed_run) for (int i = 4; i <= 6; i++) HIPCHK(e, hipEventRecord(e->ev[i], s));
+  } else {
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
+    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
+    HIPCHK(e, launch_compact(g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
+                             e->capacity, e->d_res, s));
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[6], s));
+  }
   HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipEventRecord(e->ev_done, s));
   e->issued = true;
@@ -576,10 +594,19 @@ int mij_encode_entropy_sizes(mij_encoder *e, uint64_t *d_size_slot, void *stream
     if (rc) return rc;
     e->static_tables_ready = true;
   }
-  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
-  HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
-  HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s,
-                        reinterpret_cast<unsigned long long *>(d_size_slot)));
+  unsigned long long *slot = reinterpret_cast<unsigned long long *>(d_size_slot);
+  if (e->fuse) {
+    // fused coder; behind it the unfused kernels, GATED on its give-up flag: they fall through unless an interval held an
+    // oversized block (rare), in which case they redo sizes and placement for the whole strip -- still without the host
+    HIPCHK(e, launch_encode_fused(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, e->d_status,
+                                  e->d_redo, e->d_out + HDR_AREA, e->capacity, e->d_res, slot, s));
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s, e->d_redo));
+    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s, slot, e->d_redo));
+  } else {
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
+    HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s, slot));
+  }
   e->timed_run = false;
   return MIJ_OK;
 }
@@ -591,7 +618,7 @@ int mij_encode_place(mij_encoder *e, uint8_t *d_file_scan, size_t file_scan_capa
   hipStream_t s = (hipStream_t)stream;
   uint8_t *own_scan = e->d_out + HDR_AREA;
   HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, own_scan, e->capacity,
-                           e->d_res, s));
+                           e->d_res, s, e->fuse ? e->d_redo : nullptr));      // fused: only if the fused placement was given up
   if (rank > 0) {
     if (!d_file_scan) return fail(e, MIJ_ERR_INVALID_ARG, "ranks > 0 need rank 0's scan area (mij_ipc_open)");
     HIPCHK(e, launch_put(own_scan, reinterpret_cast<const unsigned long long *>(d_sizes), rank, world, d_file_scan, file_scan_capacity,
@@ -714,6 +741,8 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
     e->d_out = nb; e->capacity = need;
     hipStream_t s = e->last_stream;
     HIPCHK(e, launch_build_tables(e->g, e->d_hist, e->p.optimized_huffman ? 1 : 0, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
+    if (e->fused_run)    // the fused coder keeps no per-interval offsets: K5 produces them for K6
+      HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
     HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
                              e->capacity, e->d_res, s));
     HIPCHK(e, hipStreamSynchronize(s));

@@ -83,15 +83,19 @@ hipError_t launch_dc_stats(const Geom &g, const int16_t *dc, uint32_t *hist, hip
 hipError_t launch_build_tables(const Geom &g, const uint32_t *hist, int optimize, const Quant *qt, DeviceTables *tab,
                                uint8_t *out, DeviceResult *res, hipStream_t s);
 hipError_t launch_encode(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
-                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, int slow, hipStream_t s);
+                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, int slow, hipStream_t s,
+                         const uint32_t *gate = nullptr);
+hipError_t launch_encode_fused(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch, size_t slot_bytes,
+                               uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, unsigned long long *status, uint32_t *redo,
+                               uint8_t *out_scan, size_t capacity, DeviceResult *res, unsigned long long *size_slot, hipStream_t s);
 hipError_t launch_scan(const uint32_t *seg_bytes, const uint32_t *seg_ff, unsigned long long *seg_off, long long nseg,
                        unsigned long long *chunk_total, unsigned long long *chunk_base, uint32_t *ovf_flag, DeviceResult *res,
-                       hipStream_t s, unsigned long long *size_slot = nullptr);
+                       hipStream_t s, unsigned long long *size_slot = nullptr, const uint32_t *gate = nullptr);
 hipError_t launch_put(const uint8_t *src, const unsigned long long *sizes, int rank, int world, uint8_t *file_scan, size_t file_capacity,
                       size_t max_bytes, DeviceResult *res, hipStream_t s);
 hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_bytes, const uint32_t *seg_bytes,
                           const unsigned long long *seg_off, const unsigned long long *chunk_base, long long nseg,
-                          uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s);
+                          uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s, const uint32_t *gate = nullptr);
 hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
 

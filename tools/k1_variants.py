@@ -14,12 +14,15 @@ CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default" is what ships
     "default": {},
-    "k4_nofallback": {"MIJ_K4_NOFALLBACK": 1},
-    "direct_stores": {"MIJ_K1_STAGED": 0},
+    "waves2": {"MIJ_K1_WAVES": 2},
     "copies2": {"MIJ_HIST_COPIES": 2},
     "no_atomics": {"MIJ_K1_STATMODE": 1},
-    "nz_from_size": {"MIJ_K1_NZ_FROM_SIZE": 1},
+    "conflict_free": {"MIJ_K1_STATMODE": 2},
+    "nostore": {"MIJ_K1_NOSTORE": 1},
+    "noload": {"MIJ_K1_NOLOAD": 1},
 }
+if os.environ.get("MIJ_VARIANTS"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
 
 
 def build():

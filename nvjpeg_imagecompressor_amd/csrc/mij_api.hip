@@ -34,6 +34,8 @@ struct mij_encoder {
     size_t slot = 0;
     uint8_t *scratch = nullptr;
     uint32_t *seg_bytes = nullptr, *seg_ff = nullptr, *hist = nullptr, *ovf = nullptr;
+    uint8_t *flag = nullptr;          // per interval: 1 = the lane-per-block coder left it to the serial kernel
+    bool fast = false;                // scan coded by k_encode_prog2.inc
     unsigned long long *seg_off = nullptr, *chunk_total = nullptr, *chunk_base = nullptr;
     DeviceTables *tab = nullptr;
     DeviceResult *res = nullptr;
@@ -292,7 +294,7 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
                                       {1, 0, 1, 63, 2, 1}, {3, 0, 0, 0, 1, 0}, {1, 2, 1, 63, 1, 0}, {1, 1, 1, 63, 1, 0}, {1, 0, 1, 63, 1, 0}};
     size_t total = 0;
     auto take = [&](size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
-    size_t o_scr[10], o_sb[10], o_sf[10], o_so[10], o_ct[10], o_cb[10], o_h[10], o_t[10], o_r[10], o_v[10];
+    size_t o_scr[10], o_sb[10], o_sf[10], o_so[10], o_ct[10], o_cb[10], o_h[10], o_t[10], o_r[10], o_v[10], o_f[10];
     for (int i = 0; i < 10; i++) {
       mij_encoder::ProgScan &q = e->ps[i];
       ScanDesc &sd = q.sd;
@@ -314,7 +316,8 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
       const size_t nch = (size_t)((q.nseg + 1023) / 1024);
       o_scr[i] = take(q.slot * (size_t)q.nseg); o_sb[i] = take((size_t)q.nseg * 4); o_sf[i] = take((size_t)q.nseg * 4);
       o_so[i] = take((size_t)q.nseg * 8); o_ct[i] = take(nch * 8); o_cb[i] = take(nch * 8); o_h[i] = take(4 * 257 * 4);
-      o_t[i] = take(sizeof(DeviceTables)); o_r[i] = take(sizeof(DeviceResult)); o_v[i] = take(4);
+      o_t[i] = take(sizeof(DeviceTables)); o_r[i] = take(sizeof(DeviceResult)); o_v[i] = take(4); o_f[i] = take((size_t)q.nseg);
+      q.fast = prog2_supported(sd) && getenv("MIJ_PROG_SERIAL") == nullptr;   // A/B switch: the lane-per-interval kernel only
     }
     CRCHK(hipMalloc(&e->d_prog, total));
     for (int i = 0; i < 10; i++) {
@@ -323,6 +326,8 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
       q.seg_off = (unsigned long long *)(e->d_prog + o_so[i]); q.chunk_total = (unsigned long long *)(e->d_prog + o_ct[i]);
       q.chunk_base = (unsigned long long *)(e->d_prog + o_cb[i]); q.hist = (uint32_t *)(e->d_prog + o_h[i]);
       q.tab = (DeviceTables *)(e->d_prog + o_t[i]); q.res = (DeviceResult *)(e->d_prog + o_r[i]); q.ovf = (uint32_t *)(e->d_prog + o_v[i]);
+      q.flag = e->d_prog + o_f[i];
+      CRCHK(hipMemset(q.flag, 0, (size_t)q.nseg));
       CRCHK(hipMemset(q.ovf, 0, 4));
     }
     CRCHK(hipHostMalloc(&e->h_prog_tab, 10 * sizeof(DeviceTables), hipHostMallocDefault));
@@ -397,6 +402,7 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   a.dc = e->d_dc + (size_t)skip * g.bpm;
   a.recip_dev = &e->d_qt->recip[0][0];
   a.hist = (e->p.optimized_huffman && !e->p.progressive) ? e->d_hist : nullptr;   // progressive gathers per scan instead
+  a.write_dc = e->p.progressive ? 1 : 0;
   if (sub.mcu_count > 0) HIPCHK(e, launch_transform(sub, a, interleaved ? 1 : 0, s));
   if (last) {
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
@@ -445,7 +451,8 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
     if (i < 4) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
     if (q.sd.kind != 2) {
       HIPCHK(e, hipMemsetAsync(q.hist, 0, 4 * 257 * sizeof(uint32_t), st));
-      HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+      if (q.fast) HIPCHK(e, launch_prog2(g, q.sd, 1, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st));
+      else HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
       // K3 builds all four tables: give the ones this scan does not use a single count so that they are well formed
       for (int w = 0; w < 4; w++) {
         const bool used = q.sd.kind == 1 ? (w == 0 || w == 2) : (w == (q.sd.comp[0] ? 3 : 1));
@@ -455,7 +462,11 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
       HIPCHK(e, launch_build_tables(g, q.hist, 1, e->d_qt, q.tab, e->d_out, q.res, st));
       HIPCHK(e, hipMemcpyAsync(&e->h_prog_tab[i], q.tab, sizeof(DeviceTables), hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+    if (q.fast) {
+      // lane per block; intervals it hands back (forced flushes of jcphuff.c, oversized blocks) go through the serial kernel
+      HIPCHK(e, launch_prog2(g, q.sd, 0, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st));
+      if (q.sd.kind >= 3) HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st, q.flag));
+    } else HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
     HIPCHK(e, launch_scan(q.seg_bytes, q.seg_ff, q.seg_off, q.nseg, q.chunk_total, q.chunk_base, q.ovf, q.res, st));
     HIPCHK(e, hipMemcpyAsync(&e->h_prog_res[i], q.res, sizeof(DeviceResult), hipMemcpyDeviceToHost, st));
   }

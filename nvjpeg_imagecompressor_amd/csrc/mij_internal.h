@@ -74,7 +74,8 @@ struct TransformArgs {
                           // arguments the 128 values were parked in SGPRs for the whole kernel and spilled through v_writelane;
                           // regrouped for one 64-byte load per column pair they were 1.3 % slower than these 8-byte loads)
   uint32_t *hist;         // non-null: optimised Huffman, take AC statistics (rows 1 and 3 of the 4 x 257 table)
-  int16_t *dc;            // compact DC array [strip blocks] (written when hist != null)
+  int16_t *dc;            // compact DC array [strip blocks] (written when hist != null, or when write_dc is set)
+  int write_dc;           // progressive output: the DC scans read the compact array instead of whole blocks
 };
 
 // launchers (mij_kernels.hip)
@@ -128,7 +129,13 @@ hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *
                               long long nseg, const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
 // Progressive scans (k_encode_prog.inc): gather != 0 counts symbols into hist (4 x 257), otherwise writes the interval slots.
 hipError_t launch_prog_encode(const Geom &g, const ScanDesc &sd, int gather, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
-                              size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, long long nseg, hipStream_t s);
+                              size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, long long nseg, hipStream_t s,
+                              const uint8_t *only_flagged = nullptr);
+// Lane-per-block form (k_encode_prog2.inc); seg_flag[interval] = 1 where the emit pass left an interval to the serial kernel.
+bool prog2_supported(const ScanDesc &sd);
+hipError_t launch_prog2(const Geom &g, const ScanDesc &sd, int gather, const int16_t *coef, const int16_t *dc, const DeviceTables *tab,
+                        uint8_t *scratch, size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, uint8_t *seg_flag,
+                        long long nseg, hipStream_t s);
 // Parallel (self-synchronising) decode of a baseline interleaved scan. `ws` is a workspace of par_workspace_bytes().
 size_t par_workspace_bytes(size_t scan_len, long long nseg);
 hipError_t launch_par_decode(const Geom &g, const uint8_t *scan, size_t n, const unsigned long long *seg_pos, long long nseg,

@@ -7,7 +7,8 @@
 //   K4 k_encode        Huffman coding + bit packing, one restart interval per wavefront                (A5+A7)
 //   K5 k_scan          exclusive scan of interval sizes                                                (A7)
 //   K6 k_compact       FF00 byte stuffing + compaction + RSTn / EOI markers                            (A7)
-//   KP k_prog_encode   progressive (SOF2) scans: libjpeg's script, gather / emit per scan, lane per restart interval   (k_encode_prog.inc)
+//   KP2 k_prog2_dc/_ac  progressive (SOF2) scans: libjpeg's script, gather / emit per scan, LANE PER BLOCK, end-of-band runs resolved with wave ballots (k_encode_prog2.inc)
+//   KP k_prog_encode   the same scans lane per restart interval: exact serial fallback for intervals KP2 hands back   (k_encode_prog.inc)
 // and, for the decode half (nvjpegDecodeJpeg*, ImageCompressorImpl.cu:361-366; getCVImageOnCPU, .cu:184-232):
 //   D1 k_rst_count/write   restart-marker positions                                                    (k_decode.inc)
 //   D2p k_par_decode<0..3> subsequence-parallel, self-synchronising Huffman decode of baseline scans   (k_decode_par.inc)
@@ -32,6 +33,7 @@ namespace mij {
 #include "k_encode.inc"
 #include "k_finish.inc"
 #include "k_encode_prog.inc"
+#include "k_encode_prog2.inc"
 #include "k_synth.inc"
 #include "k_decode.inc"
 #include "k_decode_scans.inc"

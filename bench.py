@@ -283,6 +283,8 @@ def main():
         kname = {"transform": "k_transform", "entropy": "k_encode", "compact": "k_compact"}
         stage_roof = {}
         for k in kname:
+            if args.progressive and k != "transform":
+                continue          # progressive: the ten scans are reported together under stage_ms["tables"]
             if stages.get(k, 0) > 0:
                 gbs = bpp[k] * strip_px / (stages[k] * 1e-3) / 1e9
                 stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),

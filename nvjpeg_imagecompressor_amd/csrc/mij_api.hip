@@ -36,6 +36,7 @@ struct mij_encoder {
     uint32_t *seg_bytes = nullptr, *seg_ff = nullptr, *hist = nullptr, *ovf = nullptr;
     uint8_t *flag = nullptr;          // per interval: 1 = the lane-per-block coder left it to the serial kernel
     bool fast = false;                // scan coded by k_encode_prog2.inc
+    int stream_index = 0;
     unsigned long long *seg_off = nullptr, *chunk_total = nullptr, *chunk_base = nullptr;
     DeviceTables *tab = nullptr;
     DeviceResult *res = nullptr;
@@ -445,18 +446,43 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
   const Geom &g = e->g;
   static const uint32_t one = 1;
   HIPCHK(e, hipEventRecord(e->prog_ev[4], s));            // the coefficients (K1 on `s`) are ready
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
+  // The ten scans only READ the coefficients, so any of them may run beside any other. They go to the four streams longest
+  // first, each to the stream with the least work queued (cost ~ blocks x band width, refinement scans twice that: the two Y
+  // refinement scans are a third of all the work and must not share a stream, which the file order i & 3 made them do).
+  int order[10], owner[10];
+  double cost[10], load[4] = {0, 0, 0, 0};
   for (int i = 0; i < 10; i++) {
+    const ScanDesc &sd = e->ps[i].sd;
+    order[i] = i;
+    cost[i] = (double)sd.nmcu * (sd.kind <= 2 ? 1.5 * (sd.kind == 1 ? 2 : 1) : (sd.Se - sd.Ss + 1) * (sd.kind == 4 ? 2.0 : 1.0));
+  }
+  static const int nstreams = getenv("MIJ_PROG_STREAMS") ? std::min(4, std::max(1, atoi(getenv("MIJ_PROG_STREAMS")))) : 3;   // experiment knobs; measured at the full size:
+  // 1 stream 7.06 ms, 2: 6.16, 3: 5.87, 4: 6.56 (longest first) / 6.40, 6.04, 6.00 (file order): the scan kernels nearly fill the chip alone
+  static const int lpt = getenv("MIJ_PROG_ORDER") ? atoi(getenv("MIJ_PROG_ORDER")) : 1;
+  if (lpt) std::sort(order, order + 10, [&](int a, int b) { return cost[a] > cost[b]; });
+  for (int k = 0; k < 10; k++) {
+    int best = 0;
+    for (int q4 = 1; q4 < nstreams; q4++) if (load[q4] < load[best]) best = q4;
+    if (!lpt) best = order[k] % nstreams;
+    owner[order[k]] = best; load[best] += cost[order[k]];
+  }
+  for (int k = 0; k < 10; k++) {
+    const int i = order[k];
     mij_encoder::ProgScan &q = e->ps[i];
-    hipStream_t st = e->prog_stream[i & 3];
-    if (i < 4) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
+    hipStream_t st = e->prog_stream[owner[i]];
+    q.stream_index = owner[i];
     if (q.sd.kind != 2) {
       HIPCHK(e, hipMemsetAsync(q.hist, 0, 4 * 257 * sizeof(uint32_t), st));
+      // (K3 builds all four tables; the ones this scan does not use get a single count so that they are well formed:
+      //  the lane-per-block gather kernels write it themselves, the serial one gets it by copy)
       if (q.fast) HIPCHK(e, launch_prog2(g, q.sd, 1, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st));
-      else HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
-      // K3 builds all four tables: give the ones this scan does not use a single count so that they are well formed
-      for (int w = 0; w < 4; w++) {
-        const bool used = q.sd.kind == 1 ? (w == 0 || w == 2) : (w == (q.sd.comp[0] ? 3 : 1));
-        if (!used) HIPCHK(e, hipMemcpyAsync(q.hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, st));
+      else {
+        HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+        for (int w = 0; w < 4; w++) {
+          const bool used = q.sd.kind == 1 ? (w == 0 || w == 2) : (w == (q.sd.comp[0] ? 3 : 1));
+          if (!used) HIPCHK(e, hipMemcpyAsync(q.hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, st));
+        }
       }
       // (K3 also writes a baseline header into the first HDR_AREA bytes of d_out; the progressive file starts after them)
       HIPCHK(e, launch_build_tables(g, q.hist, 1, e->d_qt, q.tab, e->d_out, q.res, st));
@@ -528,7 +554,7 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
   for (int i = 0; i < 10; i++) {
     const mij_encoder::ProgScan &q = e->ps[i];
     HIPCHK(e, launch_compact(g2, q.scratch, q.slot, q.seg_bytes, q.seg_off, q.chunk_base, q.nseg, file + data_off[i], e->capacity - data_off[i],
-                             q.res, e->prog_stream[i & 3]));
+                             q.res, e->prog_stream[q.stream_index]));
   }
   for (int q4 = 0; q4 < 4; q4++) {
     HIPCHK(e, hipEventRecord(e->prog_ev[q4], e->prog_stream[q4]));

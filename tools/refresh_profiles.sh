@@ -9,6 +9,7 @@ step "bench default";      timeout -k 10 400 python bench.py > $O/bench_n1.json 
 step "bench fixed";        timeout -k 10 300 python bench.py --no-optimize --no-cpu-baseline > $O/bench_fixed.json 2>> $O/bench_n1.err || exit 1
 step "bench progressive";  timeout -k 10 300 python bench.py --progressive --no-cpu-baseline > $O/bench_prog.json 2>> $O/bench_n1.err || exit 1
 step "bench two streams";  timeout -k 10 300 python bench.py --two-streams --no-cpu-baseline > $O/bench_two_streams.json 2>> $O/bench_n1.err || exit 1
+step "bench 440 (IJG cpu leg)"; timeout -k 10 300 python bench.py --css 440 --steps 50 > $O/bench_440_cpu.json 2>> $O/bench_n1.err || exit 1
 : > $O/table1.jsonl
 for css in 444 422 440 420 411; do
   step "sampling $css"; timeout -k 10 300 python bench.py --css $css --no-cpu-baseline 2>> $O/bench_n1.err | tail -1 >> $O/table1.jsonl || exit 1

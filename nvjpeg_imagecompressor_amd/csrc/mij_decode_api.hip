@@ -28,6 +28,7 @@ struct mij_decoder {
   uint8_t *d_par_ws = nullptr; size_t par_ws_cap = 0;   // workspace of the parallel baseline decoder
   // generic route: independent scans run concurrently, each with its own restart-position workspace
   unsigned long long *d_scan_ws = nullptr; size_t scan_ws_cap = 0;
+  uint8_t *d_clean = nullptr; size_t clean_cap = 0;      // un-stuffed copies of the scans that have no restart markers (k_decode_wave.inc)
   hipStream_t aux[4]{};
   std::vector<hipEvent_t> scan_ev;
   hipEvent_t ev_ready{};
@@ -275,7 +276,7 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws); (void)hipFree(d->d_clean);
   if (d->aux_ok) { for (auto &q : d->aux) (void)hipStreamDestroy(q); (void)hipEventDestroy(d->ev_ready); }
   for (auto &v : d->scan_ev) (void)hipEventDestroy(v);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
@@ -413,16 +414,21 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
       d->scan_ev.push_back(ev);
     }
     // per-scan workspace: restart positions (ns + 1) and two chunk-count arrays
-    std::vector<size_t> o_seg(ps.scans.size()), o_cnt(ps.scans.size()), o_base(ps.scans.size());
-    size_t words = 0;
+    std::vector<size_t> o_seg(ps.scans.size()), o_cnt(ps.scans.size()), o_base(ps.scans.size()), o_len(ps.scans.size()), o_clean(ps.scans.size());
+    size_t words = 0, clean_bytes = 0;
+    static const bool lanes_only = getenv("MIJ_DECODE_SCAN_LANES") != nullptr;   // A/B switch: the one-lane walk for scans without restart markers
     for (size_t i = 0; i < ps.scans.size(); i++) {
       const ScanInfo &sc = ps.scans[i];
       const size_t ns = sc.sd.ri > 0 ? (size_t)((sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri) : 1, nch = (sc.len + 16383) / 16384 + 1;
       o_seg[i] = words; words += ns + 1;
       o_cnt[i] = words; words += nch;
       o_base[i] = words; words += nch + 1;
+      o_len[i] = words; words += 1;
+      o_clean[i] = clean_bytes;
+      if (sc.sd.ri == 0 && !lanes_only) clean_bytes += (sc.len + 256 + 255) & ~(size_t)255;
     }
     if ((rc = ensure(d, d->d_scan_ws, d->scan_ws_cap, words))) return rc;
+    if (clean_bytes && (rc = ensure(d, d->d_clean, d->clean_cap, clean_bytes))) return rc;
     DHIP(d, hipEventRecord(d->ev_ready, s));
     for (auto &q : d->aux) DHIP(d, hipStreamWaitEvent(q, d->ev_ready, 0));
     for (size_t i = 0; i < ps.scans.size(); i++) {
@@ -445,9 +451,15 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
       const uint8_t *base = d->d_scan + (sc.off - data_off);
       const long long ns = sc.sd.ri > 0 ? (sc.sd.nmcu + sc.sd.ri - 1) / sc.sd.ri : 1;
       unsigned long long *seg = d->d_scan_ws + o_seg[i];
-      if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], seg, ns, d->d_flags, d->d_res, q));
-      else DHIP(d, hipMemsetAsync(seg, 0, sizeof(unsigned long long), q));
-      DHIP(d, launch_scan_decode(g, sc.sd, base, sc.len, seg, ns, d->d_tabs + i, d->d_coef, d->d_flags + 1, q));
+      if (sc.sd.ri == 0 && !lanes_only) {
+        // no restart markers: the scan is one chain of symbols -- a whole wave walks it (k_decode_wave.inc)
+        DHIP(d, launch_scan_decode_wave(g, sc.sd, base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], d->d_scan_ws + o_len[i],
+                                        d->d_clean + o_clean[i], d->d_tabs + i, d->d_coef, d->d_flags, d->d_res, d->d_flags + 1, q));
+      } else {
+        if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], seg, ns, d->d_flags, d->d_res, q));
+        else DHIP(d, hipMemsetAsync(seg, 0, sizeof(unsigned long long), q));
+        DHIP(d, launch_scan_decode(g, sc.sd, base, sc.len, seg, ns, d->d_tabs + i, d->d_coef, d->d_flags + 1, q));
+      }
       DHIP(d, hipEventRecord(d->scan_ev[i], q));
     }
     for (size_t i = 0; i < ps.scans.size(); i++) DHIP(d, hipStreamWaitEvent(s, d->scan_ev[i], 0));

@@ -127,6 +127,9 @@ struct ScanDesc {
 
 hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, const unsigned long long *seg_pos,
                               long long nseg, const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
+hipError_t launch_scan_decode_wave(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, unsigned long long *cnt,
+                                   unsigned long long *base, unsigned long long *clean_len, uint8_t *clean, const DecTables *tab,
+                                   int16_t *coef, uint32_t *scratch_flag, DeviceResult *scratch_res, uint32_t *err_flag, hipStream_t s);
 // Progressive scans (k_encode_prog.inc): gather != 0 counts symbols into hist (4 x 257), otherwise writes the interval slots.
 hipError_t launch_prog_encode(const Geom &g, const ScanDesc &sd, int gather, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
                               size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, long long nseg, hipStream_t s,

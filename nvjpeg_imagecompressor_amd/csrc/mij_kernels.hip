@@ -13,7 +13,8 @@
 //   D1 k_rst_count/write   restart-marker positions                                                    (k_decode.inc)
 //   D2p k_par_decode<0..3> subsequence-parallel, self-synchronising Huffman decode of baseline scans   (k_decode_par.inc)
 //   D2 k_huff_decode       lane per restart interval (fallback)                                        (k_decode.inc)
-//   D2s k_scan_decode      progressive / multi-scan / greyscale scans                                  (k_decode_scans.inc)
+//   D2s k_scan_decode      progressive / multi-scan / greyscale scans, lane per restart interval       (k_decode_scans.inc)
+//   D2w k_scan_decode_wave the same scans when they have NO restart markers: one wave walks the chain   (k_decode_wave.inc)
 //   D3 k_idct, D4 k_upsample_color[8], k_residual   IDCT, upsampling + colour, difference map          (k_decode.inc)
 // Bit-identity with stock JPEG codecs means following their integer procedures: the "islow" FDCT / IDCT factorisation and
 // constants, the colour / downsampling rounding rules, the quantiser and the optimal-table and progressive procedures are
@@ -37,6 +38,7 @@ namespace mij {
 #include "k_synth.inc"
 #include "k_decode.inc"
 #include "k_decode_scans.inc"
+#include "k_decode_wave.inc"
 #include "k_decode_par.inc"
 #include "k_launch.inc"
 

@@ -22,6 +22,7 @@ import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL and the peer-mapped gather buffers need on this host driver
 
 W_IMG, H_IMG, QUALITY, CSS_NAME = 8320, 40000, 95, "422"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -240,12 +241,16 @@ def main():
         # The put pipeline records no per-stage events (nothing in it touches the host). For the stage table, code one more
         # image the host-synchronised way, outside the timed region, with events on.
         jpeg_keep = jpeg_t.clone() if jpeg_t is not None else None
-        if enc is not None:
-            enc.enable_timing(True)
-        sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
-        if enc is not None:
-            record_times(enc)
-        steps_timed = 1
+        try:
+            if enc is not None:
+                enc.enable_timing(True)
+            sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+            if enc is not None:
+                record_times(enc)
+            steps_timed = 1
+        except Exception as ex:      # noqa: BLE001 -- the stage table is informational; the measured value stands without it
+            print("stage-time pass failed: %r" % (ex,), file=sys.stderr)
+            stage_acc.clear()
         fence()
         jpeg_t = jpeg_keep
 

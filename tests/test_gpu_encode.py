@@ -153,3 +153,28 @@ def test_output_larger_than_the_preallocated_buffer(mij, oracle):
             assert len(got) > (W // 8) * (H // 8) * 3 * 64 + 65536
             assert got == oracle.encode(img, 100, 0, optimize, 1)
             assert enc.encode_host(img, "rgb") == got          # and again, now that the buffer is large enough
+
+
+def test_fused_entropy_coder_opt_in_matches_oracle(oracle, tmp_path):
+    """MIJ_FUSE=1 (opt-in experiment): K4 with the size scan and the stuffing + compaction folded in by a decoupled
+    look-back. Slower than the three kernels, but it must stay exact, including an image whose blocks overflow the fast
+    coder's strips (noise at q100) and a buffer that has to grow."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, zlib, numpy as np
+sys.path.insert(0, %r)
+import nvjpeg_imagecompressor_amd as mij
+from oracle import oracle as O
+rng = np.random.default_rng(5)
+for (W, H, q, css, img) in [(2080, 1000, 95, 1, O.synth_rgb(2080, 1000)), (416, 248, 100, 0, rng.integers(0, 256, (248, 416, 3), dtype=np.uint8)),
+                            (333, 77, 35, 2, O.synth_rgb(333, 77))]:
+    with mij.Encoder(W, H, q, True, css) as enc:
+        got = enc.encode_host(img, "rgb")
+        ri = enc.geometry["restart_interval"]
+    want = O.encode(img, q, css, True, ri)
+    assert got == want, (W, H, q, css, len(got), len(want))
+print("fused ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MIJ_FUSE="1"), timeout=300)
+    assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr

@@ -190,3 +190,21 @@ def test_header_fuzz_is_rejected_cleanly(mij):
     for name, data in bad.items():
         rc, _ = _info(mij, data)
         assert rc == -6, (name, rc)
+
+
+def test_geometry_query_needs_no_device(mij):
+    """mij_geometry_query is pure arithmetic: a sharding host cuts its strips with it before any handle exists. It must agree
+    with the oracle's geometry and validate like mij_encoder_create."""
+    from oracle import oracle as O
+    for (W, H, css) in [(8320, 40000, 1), (8320, 40000, 2), (208, 250, 1), (333, 77, 0), (17, 33, 4), (64, 64, 5)]:
+        g = mij.geometry_query(W, H, 95, True, css)
+        og = O.geometry(W, H, css)
+        assert (g["mcus_per_row"], g["mcu_rows"], g["hs"], g["vs"]) == (og["mcux"], og["mcuy"], og["hs"], og["vs"])
+        assert g["strip_first_mcu"] == 0 and g["strip_mcus"] == og["mcux"] * og["mcuy"] and g["strip_rows"] == H
+        assert 1 <= g["restart_interval"] <= 65535
+    assert mij.geometry_query(8320, 40000, 95, True, 1)["restart_interval"] == 104        # the headline configuration
+    assert mij.geometry_query(8320, 40000, 95, True, 1, 112)["restart_interval"] == 112   # an interval that does not divide the row: still fine
+    with pytest.raises(mij.MiJpegError):
+        mij.geometry_query(0, 10)
+    with pytest.raises(mij.MiJpegError):
+        mij.geometry_query(64, 64, 95, True, 9)

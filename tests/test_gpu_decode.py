@@ -197,6 +197,9 @@ def test_corrupt_files_are_survivable(mij, oracle):
     with mij.Encoder(640, 480, 90, True, 2, restart_interval=7, progressive=True) as enc:
         files.append(enc.encode_host(img, "rgb"))
     b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", quality=85); files.append(b.getvalue())      # no DRI
+    # progressive WITHOUT restart markers (what nvJPEG and web files look like): every scan is walked by one wave (k_decode_wave.inc)
+    b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", quality=90, progressive=True, optimize=True); files.append(b.getvalue())
+    b = io.BytesIO(); Image.fromarray(img[..., 1], "L").save(b, "JPEG", quality=80, progressive=True); files.append(b.getvalue())
     with mij.Decoder() as dec:
         for f in files:
             variants = [f[:len(f) // 2], f[:len(f) - 200], f[:700]]
@@ -205,13 +208,13 @@ def test_corrupt_files_are_survivable(mij, oracle):
                 g = bytearray(f); g[dri + 4:dri + 6] = b"\x00\x01"; variants.append(bytes(g))
             for _ in range(6):
                 g = bytearray(f)
-                for p in rng.integers(800, len(f) - 2, 20):
+                for p in rng.integers(min(800, len(f) // 2), len(f) - 2, 20):
                     g[int(p)] = int(rng.integers(0, 256))
                 variants.append(bytes(g))
             for v in variants:
                 try:
                     out = dec.decode_host(v, "rgb")
-                    assert out.shape == (480, 640, 3)
+                    assert out.shape[:2] == (480, 640)
                 except mij.MiJpegError:
                     pass
         # and the decoder still works afterwards

@@ -223,10 +223,11 @@ class Decoder:
         return float(ms.value)
 
 
-def geometry_query(width, height, quality=95, optimized_huffman=True, css=0, restart_interval=MIJ_RESTART_AUTO):
+def geometry_query(width, height, quality=95, optimized_huffman=True, css=0, restart_interval=MIJ_RESTART_AUTO, progressive=False):
     """Geometry of the WHOLE image from the parameters alone (mij_geometry_query: no device, nothing allocated)."""
     L = _lib.load()
-    p = _lib.EncoderParams(width, height, quality, int(bool(optimized_huffman)), _css_value(css), restart_interval, 0, 0, 0, 0)
+    p = _lib.EncoderParams(width, height, quality, int(bool(optimized_huffman)), _css_value(css), restart_interval, 0, 0, 0,
+                           int(bool(progressive)))
     g = _lib.Geometry()
     rc = L.mij_geometry_query(C.byref(p), C.byref(g))
     if rc:

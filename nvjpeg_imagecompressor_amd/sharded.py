@@ -431,7 +431,7 @@ def make_hip_strip_encoder(torch, width, height, quality, optimize, css, rank, w
     if progressive:
         if world != 1:
             raise ValueError("progressive output is not sharded: every scan spans the whole image")
-        return Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, progressive=True)
+        return Encoder(width, height, quality, optimize, css, restart_interval, device_index, progressive=True)   # (its own AUTO rule: a multiple of 64 blocks)
     if r1 <= r0:
         return None
     return Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, r0, r1 - r0)

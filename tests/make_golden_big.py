@@ -16,7 +16,7 @@ W, H = 8320, 40000
 # (key, css, restart interval chosen by the encoder's AUTO rule, optimise, progressive)
 CASES = [("css1_ri104_opt", 1, 104, True, False), ("css0_ri104_opt", 0, 104, True, False), ("css2_ri52_opt", 2, 52, True, False),
          ("css3_ri80_opt", 3, 80, True, False), ("css4_ri52_opt", 4, 52, True, False), ("css1_ri104_fix", 1, 104, False, False),
-         ("css1_ri104_progressive", 1, 104, True, True)]
+         ("css1_ri104_progressive", 1, 104, True, True), ("css1_ri640_progressive", 1, 640, True, True)]
 
 
 def main():

@@ -36,13 +36,16 @@ def test_fullsize_bit_exact(mij, big_image, css, optimize):
     assert "%08x" % zlib.crc32(jpg) == GOLD["cases"][key]["crc32"]
 
 
-def test_fullsize_progressive_bit_exact(mij, big_image):
-    """Progressive output at the BASELINE size: the oracle's (= libjpeg's) file, by length and CRC."""
-    with mij.Encoder(W, H, 95, True, 1, progressive=True) as enc:
-        assert enc.geometry["restart_interval"] == 104
+@pytest.mark.parametrize("ri", [-1, 104])
+def test_fullsize_progressive_bit_exact(mij, big_image, ri):
+    """Progressive output at the BASELINE size: the oracle's (= libjpeg's) file, by length and CRC -- with the interval the
+    library picks for progressive output (a multiple of 64 blocks: 640 here) and with the baseline path's 104."""
+    with mij.Encoder(W, H, 95, True, 1, restart_interval=ri, progressive=True) as enc:
+        got_ri = enc.geometry["restart_interval"]
+        assert got_ri == (640 if ri < 0 else ri)
         enc.encode_device(big_image.data_ptr(), W * 3, "rgb")
         jpg = enc.retrieve()
-    gold = GOLD["cases"]["css1_ri104_progressive"]
+    gold = GOLD["cases"]["css1_ri%d_progressive" % got_ri]
     assert len(jpg) == gold["len"] and "%08x" % zlib.crc32(jpg) == gold["crc32"]
 
 

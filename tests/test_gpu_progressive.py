@@ -80,7 +80,7 @@ def test_facade_progressive(mij, oracle, capsys):
     r.deleteCompressEnv()
     b = io.BytesIO()
     Image.fromarray(bgr[..., ::-1]).save(b, "JPEG", quality=95, subsampling=1, progressive=True,
-                                         restart_marker_blocks=mij.Encoder(W, H, 95, True, 1).geometry["restart_interval"])
+                                         restart_marker_blocks=mij.geometry_query(W, H, 95, True, 1, progressive=True)["restart_interval"])
     assert out == b.getvalue()
 
 

@@ -63,12 +63,14 @@ typedef struct mij_encoder_params {
   int quality;             /* 1..100, IJG scaling; nvjpegEncoderParamsSetQuality (ImageCompressorImpl.cu:30) */
   int optimized_huffman;   /* nvjpegEncoderParamsSetOptimizedHuffman (ImageCompressorImpl.cu:29) */
   int css;                 /* MIJ_CSS_*; nvjpegEncoderParamsSetSamplingFactors (ImageCompressorImpl.cu:31) */
-  int restart_interval;    /* MCUs per restart interval (DRI); MIJ_RESTART_AUTO lets the library choose. The unit of
+  int restart_interval;    /* MCUs per restart interval (DRI); MIJ_RESTART_AUTO lets the library choose (an interval
+                              whose block count is a whole number of 64-block batches: 64 MCUs at 4:2:2). The unit of
                               GPU parallelism is one restart interval, so 0 (= no restart markers) is rejected. */
   int device;              /* HIP device ordinal */
   /* Strip sharding (multi-GPU). This encoder handles MCU rows [strip_mcu_row0, +strip_mcu_rows) of the
    * full image; strip_mcu_rows == 0 means the whole image. The strip's first MCU must fall on a restart-interval
-   * boundary (guaranteed when restart_interval divides the MCUs per row, which AUTO always picks). */
+   * boundary: strip_mcu_row0 * mcus_per_row must be a multiple of the interval (any row when the interval divides
+   * the MCUs per row; otherwise every lcm(interval, mcus_per_row) / mcus_per_row rows -- 8 rows at the headline size). */
   int strip_mcu_row0, strip_mcu_rows;
   /* nvjpegEncoderParamsSetEncoding (ImageCompressorImpl.cu:28): 0 = baseline sequential (SOF0, one scan), the default
    * and the fast path; 1 = progressive (SOF2): the same coefficients coded as the ten scans of libjpeg's default script
@@ -194,7 +196,9 @@ MIJ_API int mij_debug_tables(mij_encoder *enc, uint8_t *host_dst_4x273);
  *    is further cut into 1-KiB subsequences that are decoded speculatively and synchronised (k_decode_par.inc), so a file
  *    WITHOUT restart markers is as fast as one with them.
  *  - Progressive and multi-scan files: exact, one GPU lane per restart interval of each scan (k_decode_scans.inc);
- *    without restart markers that is one lane per scan -- fine for pictures, slow for hundreds of megapixels.
+ *    without restart markers one WAVE per scan (k_decode_wave.inc: the bitstream is inherently serial, the wave's 64 lanes
+ *    share the byte unstuffing, the refill and the refinement of a block) -- fine for pictures, seconds for hundreds of
+ *    megapixels.
  * Pixels are identical to libjpeg-turbo's (islow IDCT, fancy upsampling). */
 typedef struct mij_decoder mij_decoder;
 /* initDecodeEnv (ImageCompressorImpl.cu:67-95) / destoryDecodeEnv (.cu:97-117). NULL destroy is a no-op. */

@@ -123,32 +123,28 @@ static int css_factors(int css, int &hs, int &vs) {
   }
 }
 
-// Restart interval = unit of GPU parallelism (one wavefront each) and of strip sharding. AUTO picks a divisor of the
-// MCUs-per-row (so every MCU row, hence every strip, starts on an interval boundary) whose block count fills whole
-// 64-block batches as well as possible.
+// Restart interval = unit of GPU parallelism (one wavefront each) and of strip sharding. The entropy coder works through an
+// interval in batches of 64 blocks, so AUTO picks an interval whose block count is a multiple of 64 -- every batch full --
+// and about 256 blocks long: short enough that an eighth of the headline image still holds more intervals (5,078) than the
+// chip has wave slots (4,096), long enough that the per-interval work (table set-up, padding, marker) stays small.
+// Measured at the full size, 4:2:2 (MCUs = blocks per interval / ms per image): 104 = 416 / 1.446 (round 1's choice: a
+// divisor of the MCUs per row, its last batch half empty), 64 = 256 / 1.405, 96 = 384 / 1.415, 128 = 512 / 1.411,
+// 192 = 768 / 1.447. An interval need not divide the MCU row: strips of a sharded encode are then cut where interval and
+// row boundaries coincide (sharded.rows_per_restart_unit). Progressive output has its own rule below.
 static int choose_restart_interval(int mcux, int bpm, bool progressive = false, long long luma_blocks = 0) {
+  (void)mcux;
   if (progressive) {
-    // Progressive output is whole-image only, so an interval need not divide a row, and the lane-per-block coder
-    // (k_encode_prog2.inc) works through a single-component scan's interval in batches of 64 blocks: a multiple of 64 fills
-    // every batch (the baseline choice, 104 at the headline size, leaves the second batch 62 % full). How many: about
-    // two intervals of the luma scans per wave slot of the chip. Measured at the full size: 104 -> 5.9 ms, 448...896 -> 4.9-5.0,
-    // 1024 -> 5.1, 1536 -> 5.3.
+    // Progressive output is whole-image only, and the lane-per-block coder (k_encode_prog2.inc) works through a
+    // single-component scan's interval in batches of 64 blocks too. How long: about two intervals of the luma scans per wave
+    // slot of the chip. Measured at the full size: 104 -> 5.9 ms, 448...896 -> 4.9-5.0, 1024 -> 5.1, 1536 -> 5.3.
     const long long k = std::min(16LL, std::max(1LL, (luma_blocks + 64 * 4096) / (64 * 8192)));
     return (int)(64 * k);
   }
-  int best = 0;
-  double best_eff = 0;
-  for (int d = 1; d <= mcux; d++) {
-    if (mcux % d) continue;
-    const int nb = d * bpm;
-    if (nb < 128 || nb > 1024) continue;
-    const double eff = (double)nb / (64.0 * ((nb + 63) / 64));
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = d; }
-  }
-  if (best) return best;
-  if ((long long)mcux * bpm > 1024) return std::min(mcux, 65535);
-  int rows = std::max(1, 256 / (mcux * bpm));
-  return std::min(mcux * rows, 65535);
+  int gcd = 64, b = bpm;
+  while (b) { const int t = gcd % b; gcd = b; b = t; }
+  const int unit = 64 / gcd;                              // smallest interval whose block count is a multiple of 64
+  const int k = std::max(1, (256 + unit * bpm / 2) / (unit * bpm));
+  return unit * k;
 }
 
 extern "C" {

@@ -13,8 +13,11 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import oracle as O  # noqa: E402
 
 W, H = 8320, 40000
-# (key, css, restart interval chosen by the encoder's AUTO rule, optimise, progressive)
-CASES = [("css1_ri104_opt", 1, 104, True, False), ("css0_ri104_opt", 0, 104, True, False), ("css2_ri52_opt", 2, 52, True, False),
+# (key, css, restart interval, optimise, progressive): the intervals the encoder's AUTO rule picks (64 / 32 MCUs baseline, 640
+# progressive) and round 1's choices (104 / 52 / 80), which the tests keep encoding with an explicit interval
+CASES = [("css1_ri64_opt", 1, 64, True, False), ("css0_ri64_opt", 0, 64, True, False), ("css2_ri32_opt", 2, 32, True, False),
+         ("css3_ri64_opt", 3, 64, True, False), ("css4_ri32_opt", 4, 32, True, False), ("css1_ri64_fix", 1, 64, False, False),
+         ("css1_ri104_opt", 1, 104, True, False), ("css0_ri104_opt", 0, 104, True, False), ("css2_ri52_opt", 2, 52, True, False),
          ("css3_ri80_opt", 3, 80, True, False), ("css4_ri52_opt", 4, 52, True, False), ("css1_ri104_fix", 1, 104, False, False),
          ("css1_ri104_progressive", 1, 104, True, True), ("css1_ri640_progressive", 1, 640, True, True)]
 

@@ -202,7 +202,9 @@ def test_geometry_query_needs_no_device(mij):
         assert (g["mcus_per_row"], g["mcu_rows"], g["hs"], g["vs"]) == (og["mcux"], og["mcuy"], og["hs"], og["vs"])
         assert g["strip_first_mcu"] == 0 and g["strip_mcus"] == og["mcux"] * og["mcuy"] and g["strip_rows"] == H
         assert 1 <= g["restart_interval"] <= 65535
-    assert mij.geometry_query(8320, 40000, 95, True, 1)["restart_interval"] == 104        # the headline configuration
+    assert mij.geometry_query(8320, 40000, 95, True, 1)["restart_interval"] == 64         # the headline configuration: 256 blocks = 4 full batches
+    for css, bpm in ((0, 3), (1, 4), (2, 6), (3, 4), (4, 6), (5, 10)):                     # AUTO: every interval a whole number of 64-block batches
+        assert mij.geometry_query(8320, 40000, 95, True, css)["restart_interval"] * bpm % 64 == 0
     assert mij.geometry_query(8320, 40000, 95, True, 1, 112)["restart_interval"] == 112   # an interval that does not divide the row: still fine
     with pytest.raises(mij.MiJpegError):
         mij.geometry_query(0, 10)

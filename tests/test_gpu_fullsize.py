@@ -24,9 +24,12 @@ def big_image(mij):
     return d
 
 
-@pytest.mark.parametrize("css,optimize", [(1, True), (0, True), (2, True), (3, True), (4, True), (1, False)])
-def test_fullsize_bit_exact(mij, big_image, css, optimize):
-    with mij.Encoder(W, H, 95, optimize, css) as enc:
+@pytest.mark.parametrize("css,optimize,ri", [(1, True, -1), (0, True, -1), (2, True, -1), (3, True, -1), (4, True, -1), (1, False, -1),
+                                             (1, True, 104), (2, True, 52), (3, True, 80)])
+def test_fullsize_bit_exact(mij, big_image, css, optimize, ri):
+    """ri -1: the interval the library picks (whole 64-block batches: 64 or 32 MCUs); the explicit ones are round 1's, which
+    divide the MCU row instead."""
+    with mij.Encoder(W, H, 95, optimize, css, restart_interval=ri) as enc:
         ri = enc.geometry["restart_interval"]
         enc.encode_device(big_image.data_ptr(), W * 3, "rgb")
         jpg = enc.retrieve()

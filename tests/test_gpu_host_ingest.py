@@ -27,8 +27,9 @@ def test_multi_range_upload_matches_oracle(mij, oracle, w, h, css, opt):
 
 def test_full_size_from_pinned_host_memory(mij, oracle):
     """BASELINE config from host memory (31 upload ranges): the committed golden length / CRC."""
-    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "big_8320x40000_q95.json")))["cases"]["css1_ri104_opt"]
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "big_8320x40000_q95.json")))["cases"]
     W, H = 8320, 40000
+    gold = gold["css1_ri%d_opt" % mij.geometry_query(W, H, 95, True, 1)["restart_interval"]]
     img = mij.pinned_empty((H, W, 3))
     for y in range(0, H, 4000):
         img[y:y + 4000] = oracle.synth_rgb(W, H, y0=y, rows=4000)

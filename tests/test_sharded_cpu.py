@@ -227,5 +227,6 @@ def test_partition_arithmetic():
                 empty = [c[1] == c[0] for c in cuts]
                 assert empty == sorted(empty)              # empty ranks, if any, come last
     assert sharded.rows_per_restart_unit(520, 104) == 1
+    assert sharded.rows_per_restart_unit(520, 64) == 8      # the headline configuration: 625 strips of 8 MCU rows to share out
     assert sharded.rows_per_restart_unit(520, 1040) == 2
     assert sharded.rows_per_restart_unit(26, 40) == 20      # 40 MCUs and 26 per row meet again after 20 rows

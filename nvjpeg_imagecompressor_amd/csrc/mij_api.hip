@@ -71,6 +71,8 @@ struct mij_encoder {
                              // who alternates two handles on one stream keeps the GPU busy while it collects a result
   bool ev_ok = false, timing = false, timed_run = false;
   float ms[MIJ_NUM_STAGE_TIMES]{};
+  bool dc_folded = false;                                  // this image's DC statistics were taken inside k_transform
+  bool no_dc_fold = getenv("MIJ_NO_DC_FOLD") != nullptr;   // A/B switch: always use k_dc_stats
   bool transformed = false, issued = false, static_tables_ready = false, wait_event = false, sharded_pending = false;
   hipStream_t last_stream = nullptr;
 };
@@ -409,10 +411,17 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   a.recip_dev = &e->d_qt->recip[0][0];
   a.hist = (e->p.optimized_huffman && !e->p.progressive) ? e->d_hist : nullptr;   // progressive gathers per scan instead
   a.write_dc = e->p.progressive ? 1 : 0;
+  // The DC statistics come out of the same kernel when no DC prediction crosses one of its tiles (256 luma blocks): the whole
+  // strip in this one call, every tile starting a restart interval (AUTO's intervals do), no dummy blocks whose DC is
+  // patched afterwards. Otherwise k_dc_stats takes them from the compact DC array once the last range is through.
+  const int mpt = 256 / (g.hs * g.vs);
+  const bool dummies = g.mcux * g.hs > g.wib0 || g.mcuy * g.vs > g.hib0;
+  if (first) e->dc_folded = a.hist && last && !dummies && mpt % g.ri == 0 && sub.mcu_first % g.ri == 0 && !e->no_dc_fold;
+  a.fold_dc = e->dc_folded ? 1 : 0;
   if (sub.mcu_count > 0) HIPCHK(e, launch_transform(sub, a, interleaved ? 1 : 0, s));
   if (last) {
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
-    if (e->p.optimized_huffman && !e->p.progressive) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
+    if (e->p.optimized_huffman && !e->p.progressive && !e->dc_folded) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
     e->transformed = true;
   }

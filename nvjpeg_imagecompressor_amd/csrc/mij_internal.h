@@ -76,6 +76,10 @@ struct TransformArgs {
   uint32_t *hist;         // non-null: optimised Huffman, take AC statistics (rows 1 and 3 of the 4 x 257 table)
   int16_t *dc;            // compact DC array [strip blocks] (written when hist != null, or when write_dc is set)
   int write_dc;           // progressive output: the DC scans read the compact array instead of whole blocks
+  int fold_dc;            // hist != null only: the DC-difference statistics are taken here too (rows 0 and 2), from the tile's DC
+                          // terms while they sit in LDS, and the compact array is not written unless write_dc asks for it. The
+                          // caller sets it when every tile starts a restart interval (interval divides the tile's MCU count,
+                          // first MCU on an interval boundary) and no block is a dummy: then no prediction crosses a tile
 };
 
 // launchers (mij_kernels.hip)

@@ -23,7 +23,7 @@ struct mij_encoder {
   DeviceTables *d_tab = nullptr;
   uint32_t *d_hist_own = nullptr, *d_hist = nullptr;
   int16_t *d_coef = nullptr, *d_dc = nullptr;
-  size_t coef_count = 0;
+  size_t coef_count = 0, coef_alloc = 0;   // coefficients of the strip; bytes of d_coef (whole tiles)
   uint8_t *d_scratch = nullptr;
   size_t slot_bytes = 0;
   // progressive output: the ten scans run concurrently, each with its own workspace (allocated only when asked for)
@@ -274,7 +274,8 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   CRCHK(hipMalloc(&e->d_hist_own, 4 * 257 * sizeof(uint32_t)));
   CRCHK(hipMemset(e->d_hist_own, 0, 4 * 257 * sizeof(uint32_t)));
   e->d_hist = e->d_hist_own;
-  CRCHK(hipMalloc(&e->d_coef, e->coef_count * sizeof(int16_t)));
+  e->coef_alloc = (size_t)coef_tiles(g, g.mcu_count) * coef_tile_bytes(g);      // whole tiles (mij_internal.h: coefficient layout)
+  CRCHK(hipMalloc(&e->d_coef, e->coef_alloc));
   CRCHK(hipMalloc(&e->d_dc, (e->coef_count / 64) * sizeof(int16_t)));
   const size_t seg_alloc = (size_t)e->nseg, scratch_alloc = e->slot_bytes * (size_t)e->nseg;
   CRCHK(hipMalloc(&e->d_scratch, scratch_alloc));
@@ -406,8 +407,7 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   const long long skip = (long long)row0 * g.mcux;
   sub.mcu_first = g.mcu_first + skip;
   sub.mcu_count = std::min((long long)rows * g.mcux, g.mcu_count - skip);
-  a.coef = e->d_coef + (size_t)skip * g.bpm * 64;
-  a.dc = e->d_dc + (size_t)skip * g.bpm;
+  a.coef = e->d_coef; a.dc = e->d_dc; a.range_skip = skip;   // tiles and the compact DC array count from the strip's first MCU
   a.recip_dev = &e->d_qt->recip[0][0];
   a.hist = (e->p.optimized_huffman && !e->p.progressive) ? e->d_hist : nullptr;   // progressive gathers per scan instead
   a.write_dc = e->p.progressive ? 1 : 0;
@@ -958,7 +958,16 @@ int mij_debug_coefficients(mij_encoder *e, int16_t *dst, size_t count) {
   if (!e || !dst) return MIJ_ERR_INVALID_ARG;
   HIPCHK(e, hipSetDevice(e->p.device));
   HIPCHK(e, hipStreamSynchronize(e->last_stream));
-  HIPCHK(e, hipMemcpy(dst, e->d_coef, std::min(count, e->coef_count) * sizeof(int16_t), hipMemcpyDeviceToHost));
+  // the device buffer is tiled and transposed (mij_internal.h); callers get [mcu][block in MCU][64 zig-zag]
+  std::vector<uint8_t> raw(e->coef_alloc);
+  HIPCHK(e, hipMemcpy(raw.data(), e->d_coef, e->coef_alloc, hipMemcpyDeviceToHost));
+  const size_t n = std::min(count, e->coef_count);
+  for (size_t i = 0; i < n; i++) {
+    const size_t blk = i >> 6;
+    const int k = (int)(i & 63);
+    const size_t off = coef_block_offset(e->g, (long long)(blk / e->g.bpm), (int)(blk % e->g.bpm)) + (size_t)(k >> 3) * COEF_PIECE_STRIDE + (size_t)(k & 7) * 2;
+    memcpy(&dst[i], &raw[off], 2);
+  }
   return MIJ_OK;
 }
 

@@ -11,8 +11,14 @@
 namespace mij {
 
 // ---- data layout in HBM (DESIGN.md "Data layout") -------------------------------------------------------------
-// coefficients : int16 [strip_mcus][blocks_per_mcu][64], blocks in MCU (scan) order, coefficients in zig-zag order.
-//                One restart interval = `ri` consecutive MCUs = one contiguous range of this buffer.
+// coefficients : int16, zig-zag order, in TILES of 256 luma blocks (= 256 / nl MCUs, K1's unit of work) holding the tile's
+//                luma blocks (slot m * nl + s for block s of the tile's MCU m) and then its Cb and Cr blocks (slot 256 +
+//                comp * MPT + m). Slots are stored in GROUPS of 64, transposed: group = 8 rows of 1 KiB, row j = the 16-byte
+//                piece j (coefficients 8j .. 8j+7) of each of the 64 blocks. Both K1 and the entropy coders work lane-per-
+//                block, so a wave stores / loads one piece of 64 blocks as one contiguous KiB (coef_block_offset below);
+//                a block's coefficient k sits at offset + (k >> 3) * 1024 + (k & 7) * 2. (Round 1 kept blocks contiguous
+//                in scan order: K1 then staged every block through LDS to get 64-byte runs, the coders through LDS again
+//                to get from 8 lanes per block back to one.)
 // statistics   : uint32 [4][257]  DC luma, AC luma, DC chroma, AC chroma (index 256 unused on device).
 // tables       : DeviceTables (below): bits/vals for the DHT segments + the encoder LUT.
 // scratch      : uint8 [nseg][slot_bytes]  un-stuffed entropy-coded bytes of each restart interval.
@@ -59,17 +65,32 @@ struct Geom {
   // multiplication (k_common.inc div_magic) or step incrementally
   uint32_t mcux_magic;    // floor(2^32 / mcux), saturated
   uint32_t seg0;          // index of the strip's first restart interval = mcu_first / ri
+  int nl_sh, mpt_sh;      // log2(nl), log2(MCUs per tile = 256 / nl)
 };
 inline void geom_finish(Geom &g) {
   const unsigned long long m = 0x100000000ull / (unsigned)g.mcux;
   g.mcux_magic = (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m);
   g.seg0 = (uint32_t)(g.mcu_first / g.ri);
+  g.nl_sh = g.nl == 1 ? 0 : g.nl == 2 ? 1 : g.nl == 4 ? 2 : 3;
+  g.mpt_sh = 8 - g.nl_sh;
+}
+// Coefficient buffer (see "data layout" above): bytes per tile, tiles of a strip, and the byte offset of piece 0 of block `s`
+// (0 .. bpm-1, luma first) of the strip's MCU `mcu`; piece j is 1024 * j further on.
+constexpr int COEF_PIECE_STRIDE = 1024, COEF_GROUP_BYTES = 8192;
+__host__ __device__ inline size_t coef_tile_bytes(const Geom &g) { return (size_t)(256 + (2 << g.mpt_sh)) * 128; }
+__host__ __device__ inline long long coef_tiles(const Geom &g, long long mcus) { return (mcus + (1 << g.mpt_sh) - 1) >> g.mpt_sh; }
+__host__ __device__ inline size_t coef_block_offset(const Geom &g, long long mcu, int s) {
+  const long long tile = mcu >> g.mpt_sh;
+  const int m = (int)(mcu & ((1 << g.mpt_sh) - 1));
+  const int slot = s < g.nl ? (m << g.nl_sh) + s : 256 + ((s - g.nl) << g.mpt_sh) + m;
+  return (size_t)tile * coef_tile_bytes(g) + (size_t)(slot >> 6) * COEF_GROUP_BYTES + (size_t)(slot & 63) * 16;
 }
 
 struct TransformArgs {
   const uint8_t *src; size_t pitch, plane_stride;
   float fA[3], fC[3];     // colour matrix rows (Y, Cb, Cr) for the first / third stored channel, times 2^-16; G is fixed
-  int16_t *coef;
+  int16_t *coef;          // the STRIP's coefficient buffer (tiles count from the strip's first MCU)
+  long long range_skip;   // MCUs between the strip's first MCU and g.mcu_first of this call (a strip may be transformed in several ranges)
   const float *recip_dev; // Quant::recip in device memory, read with scalar loads at the point of use (by value in the kernel
                           // arguments the 128 values were parked in SGPRs for the whole kernel and spilled through v_writelane;
                           // regrouped for one 64-byte load per column pair they were 1.3 % slower than these 8-byte loads)

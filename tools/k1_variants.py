@@ -20,6 +20,10 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "conflict_free": {"MIJ_K1_STATMODE": 2},
     "nostore": {"MIJ_K1_NOSTORE": 1},
     "noload": {"MIJ_K1_NOLOAD": 1},
+    "tlayout": {"MIJ_K1_TLAYOUT": 1},
+    "tlayout_copies5": {"MIJ_K1_TLAYOUT": 1, "MIJ_HIST_COPIES": 5},
+    "tlayout_copies7": {"MIJ_K1_TLAYOUT": 1, "MIJ_HIST_COPIES": 7},
+    "tlayout_waves4": {"MIJ_K1_TLAYOUT": 1, "MIJ_K1_WAVES": 4},
 }
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}

@@ -20,10 +20,11 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "conflict_free": {"MIJ_K1_STATMODE": 2},
     "nostore": {"MIJ_K1_NOSTORE": 1},
     "noload": {"MIJ_K1_NOLOAD": 1},
-    "tlayout": {"MIJ_K1_TLAYOUT": 1},
-    "tlayout_copies5": {"MIJ_K1_TLAYOUT": 1, "MIJ_HIST_COPIES": 5},
-    "tlayout_copies7": {"MIJ_K1_TLAYOUT": 1, "MIJ_HIST_COPIES": 7},
-    "tlayout_waves4": {"MIJ_K1_TLAYOUT": 1, "MIJ_K1_WAVES": 4},
+    "copies4": {"MIJ_HIST_COPIES": 4},
+    "copies5": {"MIJ_HIST_COPIES": 5},
+    "waves4": {"MIJ_K1_WAVES": 4},
+    "c444_2": {"MIJ_HIST_COPIES_444": 2},    # these need MIJ_VARIANTS_FULL=1 (all samplings) and `run --css 444`
+    "c444_3": {"MIJ_HIST_COPIES_444": 3},
 }
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
@@ -36,7 +37,7 @@ def build():
         objs = []
         for src in ("mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip"):
             obj = os.path.join(d, src.replace(".hip", ".o"))
-            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DMIJ_FAST_BUILD",
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + ([] if os.environ.get("MIJ_VARIANTS_FULL") else ["-DMIJ_FAST_BUILD"]) + [
                    "-Rpass-analysis=kernel-resource-usage"] + ["-D%s=%s" % kv for kv in defs.items()] + ["-c", os.path.join(CSRC, src), "-o", obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode:

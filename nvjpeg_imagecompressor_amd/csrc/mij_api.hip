@@ -71,6 +71,8 @@ struct mij_encoder {
                              // who alternates two handles on one stream keeps the GPU busy while it collects a result
   bool ev_ok = false, timing = false, timed_run = false;
   float ms[MIJ_NUM_STAGE_TIMES]{};
+  bool k4_narrow = false;                                   // fast entropy coder with 16-word strips (5 waves per SIMD); see note_recoded
+  uint32_t seen_recoded = 0;
   bool dc_folded = false;                                  // this image's DC statistics were taken inside k_transform
   bool no_dc_fold = getenv("MIJ_NO_DC_FOLD") != nullptr;   // A/B switch: always use k_dc_stats
   bool transformed = false, issued = false, static_tables_ready = false, wait_event = false, sharded_pending = false;
@@ -296,7 +298,10 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   e->fuse = getenv("MIJ_FUSE") != nullptr;
   CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity + 64));
   CRCHK(hipMalloc(&e->d_res, sizeof(DeviceResult)));
+  CRCHK(hipMemset(e->d_res, 0, sizeof(DeviceResult)));
+  e->k4_narrow = p->quality <= 97 && getenv("MIJ_K4_WIDE") == nullptr;
   CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
+  memset(e->h_res, 0, sizeof(DeviceResult));
   if (p->progressive) {
     // libjpeg's jpeg_simple_progression for YCbCr (jcparam.c); a single-component scan has one block per "MCU"
     static const int script[10][6] = {{3, 0, 0, 0, 0, 1}, {1, 0, 1, 5, 0, 2}, {1, 2, 1, 63, 0, 1}, {1, 1, 1, 63, 0, 1}, {1, 0, 6, 63, 0, 2},
@@ -434,6 +439,14 @@ static int check_input(mij_encoder *e, const void *src, size_t pitch, int fmt) {
   if (!interleaved && fmt != MIJ_INPUT_RGB && fmt != MIJ_INPUT_BGR) return fail(e, MIJ_ERR_INVALID_ARG, "unknown input format");
   if (pitch < (size_t)e->g.W * (interleaved ? 3 : 1)) return fail(e, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
   return MIJ_OK;
+}
+
+// The fast entropy coder comes in two strip sizes (k_encode.inc): a handle stays on the narrow, faster one until more than
+// 1 % of an image's restart intervals overflowed it and went through the roomy coder.
+static void note_recoded(mij_encoder *e) {
+  const uint32_t d = e->h_res->recoded - e->seen_recoded;
+  e->seen_recoded = e->h_res->recoded;
+  if (e->k4_narrow && (long long)d * 100 > e->nseg) e->k4_narrow = false;
 }
 
 static int strip_mcu_rows(const Geom &g) { return (int)((g.mcu_count + g.mcux - 1) / g.mcux); }
@@ -608,7 +621,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
                                   e->d_redo, e->d_out + HDR_AREA, e->capacity, e->d_res, nullptr, s));
     if (e->timed_run) for (int i = 4; i <= 6; i++) HIPCHK(e, hipEventRecord(e->ev[i], s));
   } else {
-    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, e->k4_narrow ? 2 : 0, s));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
     HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
@@ -654,8 +667,8 @@ int mij_encode_entropy_sizes(mij_encoder *e, uint64_t *d_size_slot, void *stream
     HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s, e->d_redo));
     HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s, slot, e->d_redo));
   } else {
-    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 0, s));
-    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, e->k4_narrow ? 2 : 0, s));
+    HIPCHK(e, launch_encode(g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s, nullptr, e->d_res));
     HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s, slot));
   }
   e->timed_run = false;
@@ -695,6 +708,7 @@ int mij_sharded_result(mij_encoder *e, const uint64_t *d_sizes, int rank, int wo
   std::vector<uint64_t> sz((size_t)world);
   HIPCHK(e, hipMemcpy(sz.data(), d_sizes, sz.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIPCHK(e, hipMemcpy(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost));
+  note_recoded(e);
   if (e->h_res->flags & 3u) return fail(e, MIJ_ERR_OVERFLOW, "a strip or the assembled file exceeds its output buffer (mij_encoder_reserve_output)");
   if (e->h_res->scan_bytes > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "strip exceeds this handle's output buffer");
   uint64_t total = 0;
@@ -776,13 +790,14 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
     // Some block needed more than a fast-path strip (768 bits): the fast encoder left those intervals marked; code them
     // with the roomy instantiation, then redo scan + compaction.
     hipStream_t s = e->last_stream;
-    HIPCHK(e, launch_encode(e->g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s));
+    HIPCHK(e, launch_encode(e->g, e->d_coef, e->d_tab, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_ff, e->nseg, 1, s, nullptr, e->d_res));
     HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
     HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
                              e->capacity, e->d_res, s));
     HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipStreamSynchronize(s));
   }
+  if (!e->p.progressive) note_recoded(e);
   if (e->h_res->scan_bytes > e->capacity) {
     // Output larger than the preallocated buffer (very high quality on noise): grow it and redo header + compaction.
     const size_t need = (size_t)e->h_res->scan_bytes + 65536;

@@ -48,6 +48,8 @@ struct DeviceResult {     // written by the scan kernel, copied to pinned host m
   uint64_t scan_bytes;
   uint32_t header_bytes;
   uint32_t flags;
+  uint32_t recoded;       // running count (never reset) of intervals the roomy entropy coder had to take over
+  uint32_t pad;
 };
 
 struct Geom {
@@ -108,9 +110,11 @@ hipError_t launch_transform(const Geom &g, const TransformArgs &a, int interleav
 hipError_t launch_dc_stats(const Geom &g, const int16_t *dc, uint32_t *hist, hipStream_t s);
 hipError_t launch_build_tables(const Geom &g, const uint32_t *hist, int optimize, const Quant *qt, DeviceTables *tab,
                                uint8_t *out, DeviceResult *res, hipStream_t s);
+// mode: 0 = fast coder, 24-word strips; 2 = fast coder, 16-word strips (5 waves per SIMD); 1 = roomy coder on the intervals
+// a fast one gave up on (counts them in res->recoded when res is given)
 hipError_t launch_encode(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
-                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, int slow, hipStream_t s,
-                         const uint32_t *gate = nullptr);
+                         size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, int mode, hipStream_t s,
+                         const uint32_t *gate = nullptr, DeviceResult *res = nullptr);
 hipError_t launch_encode_fused(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch, size_t slot_bytes,
                                uint32_t *seg_bytes, uint32_t *seg_ff, long long nseg, unsigned long long *status, uint32_t *redo,
                                uint8_t *out_scan, size_t capacity, DeviceResult *res, unsigned long long *size_slot, hipStream_t s);

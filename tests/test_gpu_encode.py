@@ -141,6 +141,23 @@ def test_gpu_output_equals_committed_libjpeg_turbo_files(mij, oracle, case):
         assert enc.encode_host(img, "rgb") == want
 
 
+def test_fast_coder_falls_back_from_narrow_strips(mij, oracle):
+    """The fast entropy coder starts on 16-word strips (512 bits per block); noise at q95 overflows them in every restart
+    interval, the roomy coder takes those intervals over, and the handle moves to 24-word strips for the next image. A
+    picture in between (few or no overflows) must come out right on either. Every file equals the oracle's."""
+    rng = np.random.default_rng(21)
+    W, H = 640, 384
+    noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    half = noise.copy()
+    half[:, : W // 2] = oracle.synth_rgb(W, H)[:, : W // 2]
+    calm = oracle.synth_rgb(W, H)
+    for css in (0, 1, 2):
+        with mij.Encoder(W, H, 95, True, css) as enc:
+            ri = enc.geometry["restart_interval"]
+            for img in (calm, noise, half, calm, noise):
+                assert enc.encode_host(img, "rgb") == oracle.encode(img, 95, css, True, ri)
+
+
 def test_output_larger_than_the_preallocated_buffer(mij, oracle):
     """Black/white noise at q100 with a restart marker after every MCU: more than one byte per coefficient, the initial
     capacity. The encoder grows its output buffer and redoes header + compaction (mij_encode_result)."""

@@ -23,8 +23,9 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "copies4": {"MIJ_HIST_COPIES": 4},
     "copies5": {"MIJ_HIST_COPIES": 5},
     "waves4": {"MIJ_K1_WAVES": 4},
-    "c444_2": {"MIJ_HIST_COPIES_444": 2},    # these need MIJ_VARIANTS_FULL=1 (all samplings) and `run --css 444`
-    "c444_3": {"MIJ_HIST_COPIES_444": 3},
+    "k4_w5": {"MIJ_K4_STRIP_WORDS": 16, "MIJ_K4_WIN_WORDS": 476, "MIJ_K4_WAVES": 5},
+    "k4_s16": {"MIJ_K4_STRIP_WORDS": 16, "MIJ_K4_WIN_WORDS": 476},
+    "k4_s20": {"MIJ_K4_STRIP_WORDS": 20, "MIJ_K4_WIN_WORDS": 508},
 }
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
@@ -46,6 +47,9 @@ def build():
             if src == "mij_kernels.hip":
                 lines = r.stderr.splitlines()
                 for i, l in enumerate(lines):
+                    if "Function Name: _ZN3mij8k_encodeILi1ELb0" in l:
+                        info = [x.split("remark:")[1].split("[-R")[0].strip() for x in lines[i + 1:i + 12] if "VGPRs:" in x or "ScratchSize" in x or "Occupancy" in x or "LDS" in x]
+                        print(name, "k_encode", info)
                     if "Function Name: _ZN3mij11k_transformILi2ELi1ELb1ELb" in l:
                         info = [x.split("remark:")[1].split("[-R")[0].strip() for x in lines[i + 1:i + 12] if "VGPRs:" in x or "ScratchSize" in x or "Occupancy" in x]
                         print(name, "stats" if "Lb1ELb1" in l else "nostats", info)

@@ -38,7 +38,7 @@ def main():
         wb = int(write.get(k, 0.0) * 1024)
         kernels[k] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "launches_averaged": [nf.get(k, 0), nw.get(k, 0)]}
     print(json.dumps({
-        "workload": "8320x40000 q95 4:2:2 optimised DRI=104, 1 GPU (bench.py defaults)",
+        "workload": "8320x40000 q95 4:2:2 optimised, AUTO restart interval (64 MCUs), 1 GPU (bench.py defaults)",
         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; "
                   "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); mean per launch",
         "kernels": kernels}, indent=1))

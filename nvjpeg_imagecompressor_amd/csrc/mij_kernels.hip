@@ -2,7 +2,7 @@
 //
 // Replaces what the reference gets from nvjpegEncodeImage (reference ImageCompressorImpl.cu:280):
 //   K1 k_transform     BGR/RGB -> YCbCr, chroma downsample, level shift, 8x8 FDCT, quantise, zig-zag   (SURVEY 8a A3+A4)
-//   K2 k_histogram     DC-difference / AC run-length symbol statistics                                 (A5+A6)
+//   K2 k_dc_stats      DC-difference statistics when K1 cannot take them itself (the AC ones are always K1's)   (A5+A6)
 //   K3 k_build_tables  optimal (or Annex K) Huffman tables, encoder LUT, JFIF header                   (A6+A7)
 //   K4 k_encode        Huffman coding + bit packing, one restart interval per wavefront                (A5+A7)
 //   K5 k_scan          exclusive scan of interval sizes                                                (A7)

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--restart-interval", type=int, default=-1, help="DRI in MCUs; -1 = the library's automatic choice (the headline config)")
     ap.add_argument("--two-streams", action="store_true", help="experiment: the two images in flight run on two HIP streams, so one "
                     "image's small serial kernels overlap the other's wide ones (per-kernel event times then include the sharing)")
+    ap.add_argument("--tables-ahead", action="store_true", help="one GPU, experiment: three handles, image i's tables built on a side stream "
+                    "(mij_encode_tables) while image i-1's entropy coder runs. Measured 1.246 against 1.265 ms per image: the cross-queue "
+                    "dependency costs ~25 us of the ~45 it hides, and the wide kernels slow down a little beside it -- not the default")
     ap.add_argument("--also-two-streams", action="store_true", help="after the timed region, time the same loop on two streams as well and "
                     "report it as `two_streams` (off by default: a profiler run of the default command must see the headline loop only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,7 +125,10 @@ def main():
     # One handle per image in flight: 2 on one GPU (the host collects image i-1 while image i runs), DEPTH on N GPUs.
     whole_geo, r0_, r1_ = sharded.strip_rows(W, H, args.quality, optimize, args.css, rank, world, args.restart_interval)
     want_put = world > 1 and args.gather == "put" and os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" and not args.progressive
-    n_handles = 1 if args.progressive or (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1") else (sharded.DEPTH if want_put else 2)
+    # One GPU, optimised tables: three handles, so that image i's transform can be issued while i-1 waits for its entropy coder and
+    # i-2 for collection (tables-ahead loop below).
+    tables_ahead = world == 1 and optimize and not args.progressive and args.tables_ahead and not args.two_streams
+    n_handles = 1 if args.progressive or (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1") else (sharded.DEPTH if want_put else (3 if tables_ahead else 2))
     encs = [sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
                                            restart_interval=args.restart_interval, progressive=args.progressive) for _ in range(n_handles)]
     enc = encs[0]                     # None: this rank owns no strip (more ranks than restart-aligned strips)
@@ -163,7 +169,8 @@ def main():
     timed_handles = [] if dpipe is not None else [e for e in encs if e is not None]
     for e in timed_handles:
         e.enable_timing(True)
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": None, "transformed": None}
+    side = torch.cuda.Stream() if tables_ahead else None
     streams = [torch.cuda.current_stream().cuda_stream] * 2
     if pipelined and world == 1 and args.two_streams:
         second = torch.cuda.Stream()
@@ -181,6 +188,20 @@ def main():
             out = pipe.flush()
             if record and prev is not None:
                 record_times(prev[0].enc)
+            return out
+        if tables_ahead:                          # drain: collect the coded image, then code and collect the transformed one
+            out = None
+            if state["pending"] is not None:
+                out = state["pending"].finish_whole()
+                if record:
+                    record_times(state["pending"].enc)
+                state["pending"] = None
+            if state["transformed"] is not None:
+                last, state["transformed"] = state["transformed"], None
+                last.enc.entropy(streams[0])
+                out = last.finish_whole()
+                if record:
+                    record_times(last.enc)
             return out
         s_prev = state["pending"]
         state["pending"] = None
@@ -205,6 +226,25 @@ def main():
             out = pipe.step()                     # issues this image, then completes the previous one
             if record and prev is not None:
                 record_times(prev[0].enc)
+            return out
+        if tables_ahead:
+            # Software pipeline over three handles, all wide kernels on ONE stream (so their event times are their own):
+            #   main: K1(i)                    K4 K5 K6(i-1)                 K1(i+1) ...
+            #   side:        K3(i) -- one workgroup, ~45 us -- runs under K4(i-1) instead of leaving the device idle
+            # and the host collects image i-2 while the device is busy with the two behind it.
+            cur = strips[state["i"] % 3]
+            state["i"] += 1
+            cur.enc.transform(cur.d_img.data_ptr(), cur.pitch, cur.fmt, 0, streams[0])
+            cur.enc.tables(side.cuda_stream)
+            prev = state["transformed"]
+            if prev is not None:
+                prev.enc.entropy(streams[0])
+            out = None
+            if state["pending"] is not None:
+                out = state["pending"].finish_whole()
+                if record:
+                    record_times(state["pending"].enc)
+            state["pending"], state["transformed"] = prev, cur
             return out
         cur = strips[state["i"] & 1]
         cur.issue_whole(streams[state["i"] & 1])
@@ -319,7 +359,9 @@ def main():
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
                        "images_in_flight": n_handles, "gather": gather_mode,
-                       "streams": n_handles if dpipe is not None else (2 if (pipelined and world == 1 and args.two_streams) else 1)},
+                       "streams": n_handles if dpipe is not None else (2 if (pipelined and world == 1 and args.two_streams) else 1),
+                       "pipeline": ("tables-ahead: image i's table build (one workgroup) on a side stream under image i-1's entropy coder; "
+                                    "all other kernels of all images on one stream") if tables_ahead else None},
             "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
             "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None,
             "hbm_copy_ceiling_note": "own 16-B/lane copy kernel (k_copy16), read + write bytes; torch copy_ on the same box: %s GB/s" % (round(copy_lib_gbs, 1) if copy_lib_gbs else None), "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},

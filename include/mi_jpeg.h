@@ -132,6 +132,13 @@ MIJ_API int mij_encode_device(mij_encoder *enc, const void *d_src, size_t pitch,
 MIJ_API int mij_encode_transform(mij_encoder *enc, const void *d_src, size_t pitch, size_t plane_stride,
                                  int input_format, void *stream);
 MIJ_API int mij_encode_entropy(mij_encoder *enc, void *stream);
+/* Optional, between the two: build this image's Huffman tables and header on `stream` -- which may be another stream than
+ * the transform's; the call orders itself behind the transform and mij_encode_entropy orders itself behind it. The table
+ * build is one workgroup for ~45 us: a caller with several images in flight (two handles) issues
+ *   transform(A, main) ; tables(A, side) ; entropy(B, main) ; ...
+ * so that it runs under B's entropy coder instead of leaving the device idle. Without this call mij_encode_entropy builds
+ * the tables itself. No counterpart in the reference (nvjpegEncodeImage is one call, ImageCompressorImpl.cu:280). */
+MIJ_API int mij_encode_tables(mij_encoder *enc, void *stream);
 /* Device pointer to the 4 x 257 uint32 symbol statistics (DC luma, AC luma, DC chroma, AC chroma). */
 MIJ_API int mij_histogram_device(mij_encoder *enc, uint32_t **d_hist, size_t *count);
 /* Use caller-owned device memory (e.g. a framework tensor that a collective can reduce) for the statistics. */

@@ -19,7 +19,7 @@ STAGE_NAMES = ("transform", "statistics", "tables", "entropy", "scan", "compact"
 # every symbol include/mi_jpeg.h declares (tests/test_abi.py checks the library exports all of them)
 EXPORTS = (
     "mij_version", "mij_abi_version", "mij_source_hash", "mij_device_count", "mij_encoder_create", "mij_encoder_destroy", "mij_encoder_geometry",
-    "mij_last_error", "mij_encode_device", "mij_encode_transform", "mij_encode_entropy", "mij_histogram_device",
+    "mij_last_error", "mij_encode_device", "mij_encode_transform", "mij_encode_entropy", "mij_encode_tables", "mij_histogram_device",
     "mij_set_histogram_buffer", "mij_encode_result", "mij_retrieve_bitstream", "mij_encode_host",
     "mij_encoder_enable_timing", "mij_stage_times", "mij_debug_coefficients", "mij_debug_tables",
     "mij_synth_image_device", "mij_copy_bench_device", "mij_decoder_create", "mij_decoder_destroy", "mij_decoder_last_error", "mij_decode_info",
@@ -111,6 +111,7 @@ def load():
     L.mij_encode_device.argtypes = [vp, vp, sz, sz, C.c_int, vp]
     L.mij_encode_transform.argtypes = [vp, vp, sz, sz, C.c_int, vp]
     L.mij_encode_entropy.argtypes = [vp, vp]
+    L.mij_encode_tables.argtypes = [vp, vp]
     L.mij_histogram_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.mij_set_histogram_buffer.argtypes = [vp, vp]
     L.mij_encode_result.argtypes = [vp, C.POINTER(Result)]

@@ -56,7 +56,7 @@ struct mij_encoder {
   bool fuse = false, fused_run = false;
   uint8_t *d_out = nullptr;
   size_t capacity = 0;  // scan-data capacity (bytes after HDR_AREA)
-  DeviceResult *d_res = nullptr, *h_res = nullptr;
+  DeviceResult *d_res = nullptr, *h_res = nullptr, *h_res_dev = nullptr;   // h_res_dev: the device's address of the page-locked h_res
   uint8_t *d_src = nullptr;
   size_t d_src_bytes = 0;
   uint8_t *h_out = nullptr;
@@ -67,10 +67,14 @@ struct mij_encoder {
   hipEvent_t ev_chunk[2]{};                          // "chunk i has landed" (ping-pong)
   bool host_streams = false;
   hipEvent_t ev[8]{};
+  hipEvent_t ev_xdone{}, ev_tab{};   // transform complete / tables built (mij_encode_tables on another stream)
+  bool tables_early = false;         // this image's tables were built by mij_encode_tables
   hipEvent_t ev_done{};      // recorded behind the result copy: mij_encode_result waits for THIS encode only, so that a caller
                              // who alternates two handles on one stream keeps the GPU busy while it collects a result
   bool ev_ok = false, timing = false, timed_run = false;
   float ms[MIJ_NUM_STAGE_TIMES]{};
+  bool hist_clean[2] = {true, true};                        // own statistics buffers known to be zero (cleared at creation / by k_build_tables)
+  bool collected = true;                                    // mij_encode_result has waited for the handle's last image
   bool k4_narrow = false;                                   // fast entropy coder with 16-word strips (5 waves per SIMD); see note_recoded
   uint32_t seen_recoded = 0;
   bool dc_folded = false;                                  // this image's DC statistics were taken inside k_transform
@@ -177,7 +181,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src); (void)hipFree(e->d_sec);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
-  if (e->ev_ok) { for (auto &v : e->ev) (void)hipEventDestroy(v); (void)hipEventDestroy(e->ev_done); }
+  if (e->ev_ok) { for (auto &v : e->ev) (void)hipEventDestroy(v); (void)hipEventDestroy(e->ev_done); (void)hipEventDestroy(e->ev_xdone); (void)hipEventDestroy(e->ev_tab); }
   (void)hipFree(e->d_prog);
   if (e->h_prog_tab) (void)hipHostFree(e->h_prog_tab);
   if (e->h_prog_res) (void)hipHostFree(e->h_prog_res);
@@ -273,8 +277,8 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   CRCHK(hipMalloc(&e->d_qt, sizeof(Quant)));
   CRCHK(hipMemcpy(e->d_qt, &e->hq, sizeof(Quant), hipMemcpyHostToDevice));
   CRCHK(hipMalloc(&e->d_tab, sizeof(DeviceTables)));
-  CRCHK(hipMalloc(&e->d_hist_own, 4 * 257 * sizeof(uint32_t)));
-  CRCHK(hipMemset(e->d_hist_own, 0, 4 * 257 * sizeof(uint32_t)));
+  CRCHK(hipMalloc(&e->d_hist_own, 2 * 4 * 257 * sizeof(uint32_t)));       // two buffers, used in turn (k_build_tables clears the other one)
+  CRCHK(hipMemset(e->d_hist_own, 0, 2 * 4 * 257 * sizeof(uint32_t)));
   e->d_hist = e->d_hist_own;
   e->coef_alloc = (size_t)coef_tiles(g, g.mcu_count) * coef_tile_bytes(g);      // whole tiles (mij_internal.h: coefficient layout)
   CRCHK(hipMalloc(&e->d_coef, e->coef_alloc));
@@ -301,6 +305,7 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   CRCHK(hipMemset(e->d_res, 0, sizeof(DeviceResult)));
   e->k4_narrow = p->quality <= 97 && getenv("MIJ_K4_WIDE") == nullptr;
   CRCHK(hipHostMalloc(&e->h_res, sizeof(DeviceResult), hipHostMallocDefault));
+  { void *dp = nullptr; if (hipHostGetDevicePointer(&dp, e->h_res, 0) == hipSuccess) e->h_res_dev = (DeviceResult *)dp; else (void)hipGetLastError(); }
   memset(e->h_res, 0, sizeof(DeviceResult));
   if (p->progressive) {
     // libjpeg's jpeg_simple_progression for YCbCr (jcparam.c); a single-component scan has one block per "MCU"
@@ -352,6 +357,8 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   }
   for (auto &v : e->ev) CRCHK(hipEventCreate(&v));
   CRCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+  CRCHK(hipEventCreateWithFlags(&e->ev_xdone, hipEventDisableTiming));
+  CRCHK(hipEventCreateWithFlags(&e->ev_tab, hipEventDisableTiming));
   e->ev_ok = true;
 #undef CRCHK
   *out = e;
@@ -379,6 +386,7 @@ int mij_encoder_enable_timing(mij_encoder *e, int on) {
 int mij_set_histogram_buffer(mij_encoder *e, uint32_t *d_hist) {
   if (!e) return MIJ_ERR_INVALID_ARG;
   e->d_hist = d_hist ? d_hist : e->d_hist_own;
+  e->hist_clean[0] = e->hist_clean[1] = false;
   return MIJ_OK;
 }
 
@@ -400,8 +408,19 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
     e->last_stream = s;
     e->timed_run = e->timing;
     e->transformed = false;
+    e->tables_early = false;
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[0], s));
-    if (e->p.optimized_huffman && !e->p.progressive) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
+    if (e->p.optimized_huffman && !e->p.progressive) {
+      // The handle's own statistics buffers alternate, and the table kernel of one image clears the buffer of the next; a
+      // caller-owned buffer (sharded path: a tensor the collective reduces in place) is cleared here.
+      // (Only when the handle's previous image has been collected: its table kernel is then known to have finished, on
+      // whatever stream it ran.)
+      const bool own = e->d_hist == e->d_hist_own || e->d_hist == e->d_hist_own + 4 * 257;
+      int c = e->d_hist == e->d_hist_own ? 0 : 1;
+      if (own && e->collected && !e->hist_clean[c] && e->hist_clean[c ^ 1]) { c ^= 1; e->d_hist = e->d_hist_own + c * 4 * 257; }
+      if (!(own && e->collected && e->hist_clean[c])) HIPCHK(e, hipMemsetAsync(e->d_hist, 0, 4 * 257 * sizeof(uint32_t), s));
+      if (own) e->hist_clean[c] = false;
+    }
   }
   TransformArgs a{};
   a.src = (const uint8_t *)d_src; a.pitch = pitch; a.plane_stride = plane_stride;
@@ -428,6 +447,7 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[1], s));
     if (e->p.optimized_huffman && !e->p.progressive && !e->dc_folded) HIPCHK(e, launch_dc_stats(g, e->d_dc, e->d_hist, s));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[2], s));
+    HIPCHK(e, hipEventRecord(e->ev_xdone, s));
     e->transformed = true;
   }
   return MIJ_OK;
@@ -460,7 +480,12 @@ int mij_encode_transform(mij_encoder *e, const void *d_src, size_t pitch, size_t
 
 static int run_tail(mij_encoder *e, hipStream_t s, bool tables) {
   const Geom &g = e->g;
-  if (tables) HIPCHK(e, launch_build_tables(g, e->d_hist, e->p.optimized_huffman ? 1 : 0, e->d_qt, e->d_tab, e->d_out, e->d_res, s));
+  uint32_t *other = nullptr;
+  if (tables && e->p.optimized_huffman && !e->p.progressive) {
+    if (e->d_hist == e->d_hist_own) { other = e->d_hist_own + 4 * 257; e->hist_clean[1] = true; }
+    else if (e->d_hist == e->d_hist_own + 4 * 257) { other = e->d_hist_own; e->hist_clean[0] = true; }
+  }
+  if (tables) HIPCHK(e, launch_build_tables(g, e->d_hist, e->p.optimized_huffman ? 1 : 0, e->d_qt, e->d_tab, e->d_out, e->d_res, s, other));
   return MIJ_OK;
 }
 
@@ -599,6 +624,25 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
   return MIJ_OK;
 }
 
+int mij_encode_tables(mij_encoder *e, void *stream) {
+  if (!e) return MIJ_ERR_INVALID_ARG;
+  if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_tables called before mij_encode_transform");
+  if (e->p.progressive) return fail(e, MIJ_ERR_INVALID_ARG, "progressive output builds a table per scan inside mij_encode_entropy");
+  if (e->tables_early) return MIJ_OK;
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(e, hipStreamWaitEvent(s, e->ev_xdone, 0));
+  if (e->p.optimized_huffman || !e->static_tables_ready) {
+    int rc = run_tail(e, s, true);
+    if (rc) return rc;
+    e->static_tables_ready = true;
+  }
+  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
+  HIPCHK(e, hipEventRecord(e->ev_tab, s));
+  e->tables_early = true;
+  return MIJ_OK;
+}
+
 int mij_encode_entropy(mij_encoder *e, void *stream) {
   if (!e) return MIJ_ERR_INVALID_ARG;
   if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_entropy called before mij_encode_transform");
@@ -607,13 +651,18 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   e->last_stream = s;
   const Geom &g = e->g;
   if (e->p.progressive) return encode_progressive(e, s);
-  // Fixed (Annex K) tables and the header do not depend on the image: built once per handle.
-  if (e->p.optimized_huffman || !e->static_tables_ready) {
-    int rc = run_tail(e, s, true);
-    if (rc) return rc;
-    e->static_tables_ready = true;
+  if (e->tables_early) {
+    HIPCHK(e, hipStreamWaitEvent(s, e->ev_tab, 0));
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[7], s));      // the entropy stage starts here, not behind the tables
+  } else {
+    // Fixed (Annex K) tables and the header do not depend on the image: built once per handle.
+    if (e->p.optimized_huffman || !e->static_tables_ready) {
+      int rc = run_tail(e, s, true);
+      if (rc) return rc;
+      e->static_tables_ready = true;
+    }
+    if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
   }
-  if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[3], s));
   e->fused_run = e->fuse;
   if (e->fuse) {
     // K4 with the size scan and the stuffing + compaction folded in (k_encode<1, true>): stage times [4], [5] read 0
@@ -625,14 +674,16 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[4], s));
     HIPCHK(e, launch_scan(e->d_seg_bytes, e->d_seg_ff, e->d_seg_off, e->nseg, e->d_chunk_total, e->d_chunk_base, e->d_ovf, e->d_res, s));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[5], s));
+    // (the compaction kernel also publishes the result record to the page-locked h_res: no device-to-host copy behind it)
     HIPCHK(e, launch_compact(g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, e->d_out + HDR_AREA,
-                             e->capacity, e->d_res, s));
+                             e->capacity, e->d_res, s, nullptr, e->h_res_dev));
     if (e->timed_run) HIPCHK(e, hipEventRecord(e->ev[6], s));
   }
-  HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
+  if (e->fuse || !e->h_res_dev) HIPCHK(e, hipMemcpyAsync(e->h_res, e->d_res, sizeof(DeviceResult), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipEventRecord(e->ev_done, s));
   e->issued = true;
   e->wait_event = true;
+  e->collected = false;
   return MIJ_OK;
 }
 
@@ -786,6 +837,7 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
   HIPCHK(e, hipSetDevice(e->p.device));
   if (e->wait_event) HIPCHK(e, hipEventSynchronize(e->ev_done));   // this encode's work only (later work on the stream may still run)
   else HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  e->collected = true;
   if (e->h_res->flags & 1u) {
     // Some block needed more than a fast-path strip (768 bits): the fast encoder left those intervals marked; code them
     // with the roomy instantiation, then redo scan + compaction.
@@ -815,14 +867,18 @@ int mij_encode_result(mij_encoder *e, mij_result *o) {
   }
   if (e->timed_run) {
     // ev: 0 start, 1 after transform, 2 after statistics, 3 after tables, 4 after encode, 5 after scan, 6 after compact
+    // (tables built early on another stream: the entropy stage is timed from ev[7], and the total is the sum of the stages --
+    // the image's kernels are interleaved with another image's then)
+    float sum = 0;
     for (int i = 0; i < 6; i++) {
       float t = 0;
-      if (hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]) != hipSuccess) t = -1.f;
+      if (hipEventElapsedTime(&t, e->ev[(i == 3 && e->tables_early) ? 7 : i], e->ev[i + 1]) != hipSuccess) t = -1.f;
       e->ms[i] = t;
+      sum += t;
     }
     float t = 0;
     if (hipEventElapsedTime(&t, e->ev[0], e->ev[6]) != hipSuccess) t = -1.f;
-    e->ms[6] = t;
+    e->ms[6] = e->tables_early ? sum : t;
   }
   const size_t hb = e->h_res->header_bytes;
   o->d_buffer = e->d_out;

@@ -108,8 +108,9 @@ struct TransformArgs {
 // launchers (mij_kernels.hip)
 hipError_t launch_transform(const Geom &g, const TransformArgs &a, int interleaved, hipStream_t s);
 hipError_t launch_dc_stats(const Geom &g, const int16_t *dc, uint32_t *hist, hipStream_t s);
+// zero_hist (may be null): 4 x 257 words the kernel clears on its way out -- the statistics buffer of the handle's NEXT image
 hipError_t launch_build_tables(const Geom &g, const uint32_t *hist, int optimize, const Quant *qt, DeviceTables *tab,
-                               uint8_t *out, DeviceResult *res, hipStream_t s);
+                               uint8_t *out, DeviceResult *res, hipStream_t s, uint32_t *zero_hist = nullptr);
 // mode: 0 = fast coder, 24-word strips; 2 = fast coder, 16-word strips (5 waves per SIMD); 1 = roomy coder on the intervals
 // a fast one gave up on (counts them in res->recoded when res is given)
 hipError_t launch_encode(const Geom &g, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
@@ -125,7 +126,8 @@ hipError_t launch_put(const uint8_t *src, const unsigned long long *sizes, int r
                       size_t max_bytes, DeviceResult *res, hipStream_t s);
 hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_bytes, const uint32_t *seg_bytes,
                           const unsigned long long *seg_off, const unsigned long long *chunk_base, long long nseg,
-                          uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s, const uint32_t *gate = nullptr);
+                          uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s, const uint32_t *gate = nullptr,
+                          DeviceResult *host_res = nullptr);
 hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
 

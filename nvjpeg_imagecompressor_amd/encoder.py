@@ -66,6 +66,10 @@ class Encoder:
         _lib.check(self._L.mij_encode_transform(self._h, C.c_void_p(d_ptr), pitch, plane_stride, _FMT[fmt],
                                                 C.c_void_p(stream)), self._h, "mij_encode_transform")
 
+    def tables(self, stream=0):
+        """Optional: build the tables on `stream` (possibly another than the transform's); see mi_jpeg.h."""
+        _lib.check(self._L.mij_encode_tables(self._h, C.c_void_p(stream)), self._h, "mij_encode_tables")
+
     def entropy(self, stream=0):
         _lib.check(self._L.mij_encode_entropy(self._h, C.c_void_p(stream)), self._h, "mij_encode_entropy")
 

@@ -195,3 +195,35 @@ print("fused ok")
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MIJ_FUSE="1"), timeout=300)
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_tables_on_a_second_stream(mij, oracle):
+    """mij_encode_tables: the table build of image A issued on a side stream between A's transform and B's entropy coder (the
+    bench's loop). Files must be the oracle's, with alternating images so that a table built for the wrong image would show."""
+    import torch
+    W, H = 1040, 520
+    imgs = [oracle.synth_rgb(W, H), np.random.default_rng(4).integers(0, 256, (H, W, 3), dtype=np.uint8)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    main, side = torch.cuda.current_stream().cuda_stream, torch.cuda.Stream()
+    encs = [mij.Encoder(W, H, 90, True, 1) for _ in range(3)]
+    for e in encs:
+        e.enable_timing(True)
+    ri = encs[0].geometry["restart_interval"]
+    want = [oracle.encode(i, 90, 1, True, ri) for i in imgs]
+    got, waiting, coded = [], None, None
+    for n in range(7):
+        e = encs[n % 3]
+        e.transform(d[n & 1].data_ptr(), W * 3, "rgb", 0, main)
+        e.tables(side.cuda_stream)
+        if waiting is not None:
+            waiting.entropy(main)
+        if coded is not None:
+            got.append(coded.retrieve())
+            assert coded.stage_times()["entropy"] > 0
+        coded, waiting = waiting, e
+    got.append(coded.retrieve())
+    waiting.entropy(main)
+    got.append(waiting.retrieve())
+    assert got == [want[n & 1] for n in range(7)]
+    for e in encs:
+        e.close()

@@ -24,6 +24,7 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "copies5": {"MIJ_HIST_COPIES": 5},
     "waves4": {"MIJ_K1_WAVES": 4},
     "nz_from_size": {"MIJ_K1_NZ_FROM_SIZE": 1},
+    "noflush": {"MIJ_K1_NOFLUSH": 1},
     "k4_w5": {"MIJ_K4_STRIP_WORDS": 16, "MIJ_K4_WIN_WORDS": 476, "MIJ_K4_WAVES": 5},
     "k4_s16": {"MIJ_K4_STRIP_WORDS": 16, "MIJ_K4_WIN_WORDS": 476},
     "k4_s20": {"MIJ_K4_STRIP_WORDS": 20, "MIJ_K4_WIN_WORDS": 508},

@@ -42,7 +42,17 @@ def _worker(rank, world, port, W, H, css, optimize, out_path):
     dist.destroy_process_group()
 
 
-def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path):
+def _noise_image(W, rows):
+    """Noise in the right half (its blocks overflow the fast entropy coder's 16-word strips: the roomy coder and the handle's
+    switch to 24-word strips get exercised inside the pipeline), the synthetic picture in the left."""
+    import numpy as np
+    from oracle import oracle as O
+    full = O.synth_rgb(W, rows)
+    full[:, W // 2:] = np.random.default_rng(77).integers(0, 256, (rows, W - W // 2, 3), dtype=np.uint8)
+    return full
+
+
+def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path, noise=False):
     """sharded.DevicePipeline on real HIP handles: DEPTH images in flight, peer-mapped rank-0 buffers, k_put."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -57,8 +67,12 @@ def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_eac
     if encs[0] is not None:
         g = encs[0].geometry
         for i in range(nimg):       # image i = the synthetic image shifted down by 8 i rows (so that the strips differ per image)
-            t = torch.empty((g["strip_rows"], W, 3), dtype=torch.uint8, device=dev)
-            mij.synth_image_device(t.data_ptr(), W, g["strip_y0"] + 8 * i, g["strip_rows"], W * 3, bgr=False)
+            if noise:       # (the oracle is only the source of the test picture here, as in the CPU tests)
+                y = g["strip_y0"] + 8 * i
+                t = torch.from_numpy(_noise_image(W, H + 8 * nimg)[y:y + g["strip_rows"]].copy()).to(dev)
+            else:
+                t = torch.empty((g["strip_rows"], W, 3), dtype=torch.uint8, device=dev)
+                mij.synth_image_device(t.data_ptr(), W, g["strip_y0"] + 8 * i, g["strip_rows"], W * 3, bgr=False)
             imgs.append(t)
         torch.cuda.synchronize()
         strips = [sharded.HipStripEncoder(torch, e, imgs[0], "rgb") for e in encs]
@@ -95,14 +109,17 @@ def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_eac
     (3, 1, True, 260, 1000, True),     # interval = two MCU rows (130 MCUs per row): strips cut in units of two rows
     (5, 1, True, 3900, 480, True),     # one restart-aligned strip per 30 MCU rows: 2 units for 5 ranks, three of them own nothing
     (3, 1, True, -1, 1000, False), (5, 2, True, -1, 2504, False),
+    (3, 1, True, -1, 1000, "noise"),   # half of every image is noise: intervals overflow the narrow fast coder (collected each step)
 ])
 def test_device_pipeline_put_gather(oracle, tmp_path, world, css, optimize, ri, H, collect_each):
     import numpy as np
     W, nimg = 2080, 5
     out = str(tmp_path / "dev.jpg")
-    mp.spawn(_device_worker, args=(world, _free_port(), W, H, css, optimize, ri, nimg, collect_each, out), nprocs=world, join=True)
+    noise = collect_each == "noise"
+    collect_each = bool(collect_each)
+    mp.spawn(_device_worker, args=(world, _free_port(), W, H, css, optimize, ri, nimg, collect_each, out, noise), nprocs=world, join=True)
     dri = int(open(out + ".ri").read())
-    full = oracle.synth_rgb(W, H + 8 * nimg)
+    full = _noise_image(W, H + 8 * nimg) if noise else oracle.synth_rgb(W, H + 8 * nimg)
     for i in (range(nimg) if collect_each else [nimg - 1]):
         want = oracle.encode(np.ascontiguousarray(full[8 * i:8 * i + H]), 95, css, optimize, dri)
         got = open(out + ".%d" % i, "rb").read()

@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
-VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default" is what ships
+VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default" is what ships (K4's strip sizes are template
+    # parameters now: MIJ_K4_WIDE=1 in the environment selects the 24-word kernel at run time)
     "default": {},
     "waves2": {"MIJ_K1_WAVES": 2},
     "copies2": {"MIJ_HIST_COPIES": 2},
@@ -21,13 +22,11 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "nostore": {"MIJ_K1_NOSTORE": 1},
     "noload": {"MIJ_K1_NOLOAD": 1},
     "copies4": {"MIJ_HIST_COPIES": 4},
-    "copies5": {"MIJ_HIST_COPIES": 5},
     "waves4": {"MIJ_K1_WAVES": 4},
     "nz_from_size": {"MIJ_K1_NZ_FROM_SIZE": 1},
     "noflush": {"MIJ_K1_NOFLUSH": 1},
-    "k4_w5": {"MIJ_K4_STRIP_WORDS": 16, "MIJ_K4_WIN_WORDS": 476, "MIJ_K4_WAVES": 5},
-    "k4_s16": {"MIJ_K4_STRIP_WORDS": 16, "MIJ_K4_WIN_WORDS": 476},
-    "k4_s20": {"MIJ_K4_STRIP_WORDS": 20, "MIJ_K4_WIN_WORDS": 508},
+    "copies3": {"MIJ_HIST_COPIES": 3},
+    "nt_stores": {"MIJ_K1_NT_STORES": 1},
 }
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}

@@ -438,7 +438,7 @@ static int transform_rows(mij_encoder *e, const void *d_src, size_t pitch, size_
   // The DC statistics come out of the same kernel when no DC prediction crosses one of its tiles (256 luma blocks): the whole
   // strip in this one call, every tile starting a restart interval (AUTO's intervals do), no dummy blocks whose DC is
   // patched afterwards. Otherwise k_dc_stats takes them from the compact DC array once the last range is through.
-  const int mpt = 256 / (g.hs * g.vs);
+  const int nl_ = g.hs * g.vs, mpt = 256 / nl_ * (nl_ == 8 ? 4 : nl_ == 4 ? 2 : 1);    // MCUs a workgroup takes per pass (TCfg::SMPT)
   const bool dummies = g.mcux * g.hs > g.wib0 || g.mcuy * g.vs > g.hib0;
   if (first) e->dc_folded = a.hist && last && !dummies && mpt % g.ri == 0 && sub.mcu_first % g.ri == 0 && !e->no_dc_fold;
   a.fold_dc = e->dc_folded ? 1 : 0;

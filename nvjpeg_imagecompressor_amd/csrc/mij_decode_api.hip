@@ -28,6 +28,7 @@ struct mij_decoder {
   uint8_t *d_par_ws = nullptr; size_t par_ws_cap = 0;   // workspace of the parallel baseline decoder
   // generic route: independent scans run concurrently, each with its own restart-position workspace
   unsigned long long *d_scan_ws = nullptr; size_t scan_ws_cap = 0;
+  unsigned long long *d_clean_len = nullptr;             // fast route: length of the clean stream
   uint8_t *d_clean = nullptr; size_t clean_cap = 0;      // un-stuffed copies of the scans that have no restart markers (k_decode_wave.inc)
   hipStream_t aux[4]{};
   std::vector<hipEvent_t> scan_ev;
@@ -276,7 +277,7 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws); (void)hipFree(d->d_clean);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws); (void)hipFree(d->d_clean); (void)hipFree(d->d_clean_len);
   if (d->aux_ok) { for (auto &q : d->aux) (void)hipStreamDestroy(q); (void)hipEventDestroy(d->ev_ready); }
   for (auto &v : d->scan_ev) (void)hipEventDestroy(v);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
@@ -359,7 +360,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     max_len = std::max(max_len, sc.len);
   }
   if (ps.fast) { max_seg = (g.mcu_count + g.ri - 1) / g.ri; max_len = scan_len; }
-  const size_t nchunks = (max_len + 16383) / 16384 + 1;
+  const size_t nchunks = 2 * ((max_len + 16383) / 16384 + 1);      // (the fast route keeps two counts per chunk)
   if ((rc = ensure(d, d->d_scan, d->scan_cap, scan_len + 64 /* BitReader window slack */)) || (rc = ensure(d, d->d_coef, d->coef_cap, ncoef)) ||
       (rc = ensure(d, d->d_planes, d->planes_cap, ysz + 2 * csz)) || (rc = ensure(d, d->d_seg_pos, d->seg_cap, (size_t)max_seg + 1)) ||
       (rc = ensure(d, d->d_tabs, d->tabs_cap, ps.scans.size())))
@@ -380,18 +381,25 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   if (ps.fast) {
     DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
     DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
-    DHIP(d, launch_find_restarts(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
     static const bool lanes_only = getenv("MIJ_DECODE_LANES") != nullptr;   // A/B switch: one lane per restart interval (k_huff_decode)
     if (lanes_only) {
+      DHIP(d, launch_find_restarts(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
       DHIP(d, launch_huff_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
     } else {
-      // subsequence-parallel decode (k_decode_par.inc); its synchronisation passes are checked from the host, so this
-      // call waits for them (the IDCT / colour kernels that follow are still asynchronous)
-      if ((rc = ensure(d, d->d_par_ws, d->par_ws_cap, par_workspace_bytes(scan_len, max_seg)))) return rc;
-      DHIP(d, launch_par_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_par_ws, d->d_flags + 2, d->d_flags + 1,
-                                &d->sync_passes, s));
-      if (d->sync_passes < 0)   // the states did not settle within 64 passes (adversarial data): exact lane-per-interval decode
+      // subsequence-parallel decode (k_decode_par.inc) of an un-stuffed, marker-free copy of the scan; its synchronisation
+      // passes are checked from the host, so this call waits for them (the IDCT / colour kernels that follow are still
+      // asynchronous)
+      if ((rc = ensure(d, d->d_par_ws, d->par_ws_cap, par_workspace_bytes(scan_len, max_seg))) || (rc = ensure(d, d->d_clean, d->clean_cap, scan_len + 256)))
+        return rc;
+      if (!d->d_clean_len) DHIP(d, hipMalloc(&d->d_clean_len, sizeof(unsigned long long)));
+      DHIP(d, launch_clean_scan(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_clean, d->d_clean_len, d->d_flags,
+                                d->d_res, s));
+      DHIP(d, launch_par_decode(g, d->d_clean, scan_len, d->d_clean_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_par_ws, d->d_flags + 2,
+                                d->d_flags + 1, &d->sync_passes, s));
+      if (d->sync_passes < 0) {  // the states did not settle within 64 passes (adversarial data): exact lane-per-interval decode of the raw stream
+        DHIP(d, launch_find_restarts(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
         DHIP(d, launch_huff_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
+      }
     }
   } else {
     // generic route (k_decode_scans.inc): scans in file order into a zeroed coefficient buffer

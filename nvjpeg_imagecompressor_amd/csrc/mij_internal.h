@@ -172,8 +172,13 @@ hipError_t launch_prog2(const Geom &g, const ScanDesc &sd, int gather, const int
                         long long nseg, hipStream_t s);
 // Parallel (self-synchronising) decode of a baseline interleaved scan. `ws` is a workspace of par_workspace_bytes().
 size_t par_workspace_bytes(size_t scan_len, long long nseg);
-hipError_t launch_par_decode(const Geom &g, const uint8_t *scan, size_t n, const unsigned long long *seg_pos, long long nseg,
-                             const DecTables *tab, int16_t *coef, void *ws, uint32_t *changed, uint32_t *err_flag, int *passes, hipStream_t s);
+// The decoder reads an un-stuffed copy of the scan without its restart markers: launch_clean_scan makes it (clean: capacity >=
+// n + 64; cnt / base: 2 x (n / 16384 + 1) words each) together with the intervals' start positions in it.
+hipError_t launch_clean_scan(const uint8_t *scan, size_t n, unsigned long long *cnt, unsigned long long *base, unsigned long long *seg_pos,
+                             long long nseg, uint8_t *clean, unsigned long long *clean_len, uint32_t *flag, DeviceResult *res, hipStream_t s);
+hipError_t launch_par_decode(const Geom &g, const uint8_t *clean, size_t n, const unsigned long long *clean_len, const unsigned long long *seg_pos,
+                             long long nseg, const DecTables *tab, int16_t *coef, void *ws, uint32_t *changed, uint32_t *err_flag, int *passes,
+                             hipStream_t s);
 hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
 hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, uint8_t *dst, size_t pitch,
                                  size_t plane_stride, int out_fmt, hipStream_t s);

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--restart-interval", type=int, default=-1, help="DRI in MCUs; -1 = the library's automatic choice (the headline config)")
     ap.add_argument("--two-streams", action="store_true", help="experiment: the two images in flight run on two HIP streams, so one "
                     "image's small serial kernels overlap the other's wide ones (per-kernel event times then include the sharing)")
+    ap.add_argument("--fixed-root", action="store_true", help="N > 1, put gather: rank 0 assembles every file (default: the assembling rank "
+                    "rotates from image to image, so that the strips of consecutive images arrive over different GPUs' links)")
     ap.add_argument("--tables-ahead", action="store_true", help="one GPU, experiment: three handles, image i's tables built on a side stream "
                     "(mij_encode_tables) while image i-1's entropy coder runs. Measured 1.246 against 1.265 ms per image: the cross-queue "
                     "dependency costs ~25 us of the ~45 it hides, and the wide kernels slow down a little beside it -- not the default")
@@ -159,7 +161,8 @@ def main():
         if want_put:
             targets = sharded.open_file_targets(torch, dist, strips if enc is not None else None, rank, world, dev_index, whole_geo)
             if targets is not None:
-                dpipe = sharded.DevicePipeline(torch, dist, strips if enc is not None else None, targets, optimize, device=dev)
+                dpipe = sharded.DevicePipeline(torch, dist, strips if enc is not None else None, targets, optimize, device=dev,
+                                               rotate=not args.fixed_root)
                 gather_mode = "put"
         if dpipe is None and pipelined:
             unit = sharded.rows_per_restart_unit(whole_geo["mcus_per_row"], whole_geo["restart_interval"])
@@ -281,6 +284,17 @@ def main():
         # The put pipeline records no per-stage events (nothing in it touches the host). For the stage table, code one more
         # image the host-synchronised way, outside the timed region, with events on.
         jpeg_keep = jpeg_t.clone() if jpeg_t is not None else None
+        if dpipe.last_root != 0:      # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
+            lr = dpipe.last_root
+            nb = torch.zeros(1, dtype=torch.int64, device=dev)
+            if rank == lr:
+                nb[0] = jpeg_keep.numel()
+            dist.broadcast(nb, src=lr)
+            if rank == lr:
+                dist.send(jpeg_keep, dst=0)
+            elif rank == 0:
+                jpeg_keep = torch.empty(int(nb.item()), dtype=torch.uint8, device=dev)
+                dist.recv(jpeg_keep, src=lr)
         try:
             if enc is not None:
                 enc.enable_timing(True)
@@ -359,6 +373,7 @@ def main():
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
                        "images_in_flight": n_handles, "gather": gather_mode,
+                       "root": (None if dpipe is None else ("rank 0" if args.fixed_root else "rotating over the ranks, image by image")),
                        "streams": n_handles if dpipe is not None else (2 if (pipelined and world == 1 and args.two_streams) else 1),
                        "pipeline": ("tables-ahead: image i's table build (one workgroup) on a side stream under image i-1's entropy coder; "
                                     "all other kernels of all images on one stream") if tables_ahead else None},

@@ -148,11 +148,15 @@ MIJ_API int mij_set_histogram_buffer(mij_encoder *enc, uint32_t *d_hist);
  * one nvjpegEncodeImage call on one GPU, ImageCompressorImpl.cu:280). Per image and rank:
  *   mij_encode_transform -> [all-reduce of the statistics] -> mij_encode_entropy_sizes(&d_slot)
  *   -> [all-gather of the slots into d_sizes[world]] -> mij_encode_place(...)
- * Nothing in that sequence waits on the host. Rank 0 assembles the file in its own output buffer (reserve room for the
- * whole file with mij_encoder_reserve_output); ranks > 0 write their strip into it through a peer mapping
- * (mij_ipc_export on rank 0, mij_ipc_open on the others) at byte offset sum(d_sizes[0..rank)). The file is complete on
- * rank 0 once every rank's mij_encode_place has executed -- e.g. when a later collective on the same streams completes.
- * mij_sharded_result waits for this handle's part and reports the file (rank 0) / the strip (others). */
+ * Nothing in that sequence waits on the host. One rank -- the image's ROOT, any rank that owns a strip -- assembles the file
+ * in its own output buffer (reserve room for the whole file with mij_encoder_reserve_output) and passes d_file_scan = NULL
+ * (or its own scan area) to mij_encode_place: its strip is compacted straight to byte offset sum(d_sizes[0..rank)) of the scan
+ * area. Every other rank passes the root's scan area as it sees it through a peer mapping (mij_ipc_export on the root,
+ * mij_ipc_open on the others) and writes its strip there at its own offset. The root may differ from image to image: a
+ * root receives (world - 1) / world of every file it assembles over its inbound links, so rotating it spreads that load
+ * (DESIGN.md section 5). The file is complete on the root once every rank's mij_encode_place has executed -- e.g. when a
+ * later collective on the same streams completes. mij_sharded_result waits for this handle's part and reports the file
+ * (the root of the handle's last image) / the strip (others). */
 MIJ_API int mij_encode_entropy_sizes(mij_encoder *enc, uint64_t *d_size_slot, void *stream);
 MIJ_API int mij_encode_place(mij_encoder *enc, uint8_t *d_file_scan, size_t file_scan_capacity, const uint64_t *d_sizes, int rank,
                              int world, void *stream);

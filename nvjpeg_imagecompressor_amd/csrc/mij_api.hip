@@ -75,6 +75,7 @@ struct mij_encoder {
   float ms[MIJ_NUM_STAGE_TIMES]{};
   bool hist_clean[2] = {true, true};                        // own statistics buffers known to be zero (cleared at creation / by k_build_tables)
   bool collected = true;                                    // mij_encode_result has waited for the handle's last image
+  bool placed_as_root = false;                              // the last mij_encode_place assembled the file in this handle's buffer
   bool k4_narrow = false;                                   // fast entropy coder with 16-word strips (5 waves per SIMD); see note_recoded
   uint32_t seen_recoded = 0;
   bool dc_folded = false;                                  // this image's DC statistics were taken inside k_transform
@@ -732,15 +733,15 @@ int mij_encode_place(mij_encoder *e, uint8_t *d_file_scan, size_t file_scan_capa
   HIPCHK(e, hipSetDevice(e->p.device));
   hipStream_t s = (hipStream_t)stream;
   uint8_t *own_scan = e->d_out + HDR_AREA;
+  // The rank whose buffer receives the file (the image's ROOT: d_file_scan null or its own scan area) compacts its strip
+  // straight to its place in the file; every other rank compacts locally and puts the strip into the root's buffer.
+  const bool is_root = !d_file_scan || d_file_scan == own_scan;
+  const unsigned long long *szs = reinterpret_cast<const unsigned long long *>(d_sizes);
   HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, own_scan, e->capacity,
-                           e->d_res, s, e->fuse ? e->d_redo : nullptr));      // fused: only if the fused placement was given up
-  if (rank > 0) {
-    if (!d_file_scan) return fail(e, MIJ_ERR_INVALID_ARG, "ranks > 0 need rank 0's scan area (mij_ipc_open)");
-    HIPCHK(e, launch_put(own_scan, reinterpret_cast<const unsigned long long *>(d_sizes), rank, world, d_file_scan, file_scan_capacity,
-                         e->capacity, e->d_res, s));
-  } else if (d_file_scan && d_file_scan != own_scan) {
-    return fail(e, MIJ_ERR_INVALID_ARG, "rank 0 assembles the file in its own buffer");
-  }
+                           e->d_res, s, e->fuse ? e->d_redo : nullptr, nullptr, is_root ? szs : nullptr, rank, world));      // fused: only if the fused placement was given up
+  if (!is_root)
+    HIPCHK(e, launch_put(own_scan, szs, rank, world, d_file_scan, file_scan_capacity, e->capacity, e->d_res, s));
+  e->placed_as_root = is_root;
   HIPCHK(e, hipEventRecord(e->ev_done, s));
   e->last_stream = s;
   e->issued = true;
@@ -764,13 +765,13 @@ int mij_sharded_result(mij_encoder *e, const uint64_t *d_sizes, int rank, int wo
   if (e->h_res->scan_bytes > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "strip exceeds this handle's output buffer");
   uint64_t total = 0;
   for (int r = 0; r < world; r++) total += sz[(size_t)r];
-  if (rank == 0 && total > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "assembled file exceeds rank 0's output buffer (mij_encoder_reserve_output)");
+  if (e->placed_as_root && total > e->capacity) return fail(e, MIJ_ERR_OVERFLOW, "assembled file exceeds the root's output buffer (mij_encoder_reserve_output)");
   const size_t hb = e->h_res->header_bytes;
   o->d_buffer = e->d_out;
   o->header_offset = HDR_AREA - hb;
   o->header_bytes = hb;
   o->scan_offset = HDR_AREA;
-  o->scan_bytes = rank == 0 ? (size_t)total : (size_t)sz[(size_t)rank];
+  o->scan_bytes = e->placed_as_root ? (size_t)total : (size_t)sz[(size_t)rank];
   o->file_bytes = hb + o->scan_bytes;
   return MIJ_OK;
 }

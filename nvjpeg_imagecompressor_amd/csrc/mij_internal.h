@@ -127,7 +127,8 @@ hipError_t launch_put(const uint8_t *src, const unsigned long long *sizes, int r
 hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_bytes, const uint32_t *seg_bytes,
                           const unsigned long long *seg_off, const unsigned long long *chunk_base, long long nseg,
                           uint8_t *out_scan, size_t capacity, const DeviceResult *res, hipStream_t s, const uint32_t *gate = nullptr,
-                          DeviceResult *host_res = nullptr);
+                          DeviceResult *host_res = nullptr, const unsigned long long *root_sizes = nullptr, int root_rank = 0,
+                          int root_world = 0);     // root_sizes: the strip goes sum(root_sizes[0 .. root_rank)) bytes into out_scan
 hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
 

@@ -8,13 +8,16 @@ restart-interval boundary, so that the only data exchanged between ranks is
   1. ONE all-reduce (sum) of the 4 x 257 uint32 symbol statistics  -- only with optimised Huffman tables, because a
      single-scan baseline file can carry only one set of tables;
   2. ONE all-gather of the strips' byte counts (8 bytes per rank), device tensor to device tensor;
-  3. the gather of the finished strip bitstreams to rank 0.
+  3. the gather of the finished strip bitstreams to ONE rank, the image's root.
 
 Everything else is local arithmetic. Two orchestrations of those steps:
 
-* `DevicePipeline` (the measured path): sizes and offsets never visit the host. Rank 0 assembles the file in its own
-  output buffer; the other ranks map that buffer (hipIpc*) and PUT their strip into it at the offset a kernel computes
-  from the all-gathered sizes, over their own xGMI link. DEPTH (3) images are in flight per rank, each on its own
+* `DevicePipeline` (the measured path): sizes and offsets never visit the host. The image's root assembles the file in its
+  own output buffer; the other ranks map that buffer (hipIpc*) and PUT their strip into it at the offset a kernel computes
+  from the all-gathered sizes, over their own xGMI link. The root ROTATES over the ranks from image to image: a root takes in
+  (N - 1) / N of a file over its inbound links (one per peer, ~77 GB/s each way), which at 8 GPUs is 0.33 ms per 204-MB file --
+  more than the 0.16 ms a rank computes on its eighth of the image -- so with a fixed root the links into rank 0 would set the
+  pace; rotating spreads the inbound traffic over every GPU's links. DEPTH images are in flight per rank, each on its own
   stream and its own communicator, so that one image's collectives and its put run under the other images' kernels.
   Nothing in a steady-state step waits on the host.
 * `StripPipeline` / `encode_step` (fallback when the peer mapping is unavailable, and the simple one-image form): sizes
@@ -26,12 +29,13 @@ tests plug in the oracle) with
     transform(stream)          -> 1-D int32 tensor of 4*257 statistics (device resident for the HIP encoder)
     entropy(stream)            -> (header, scan) uint8 tensors                      [host-synchronised path]
     entropy_sizes(slot, stream)   writes the strip's byte count into the 1-element int64 tensor `slot`
-    place(target, sizes, rank, world, stream)   strip -> the assembled file at offset sum(sizes[:rank])
-    file(target, sizes, rank, world)            rank 0: the assembled file (waits for this handle's work)
+    place(target, sizes, rank, world, stream)   strip -> the assembled file at offset sum(sizes[:rank]); target None = this
+                                                rank is the image's root (the file is assembled in its own buffer)
+    file(target, sizes, rank, world)            the root (target None): the assembled file (waits for this handle's work)
 """
 from .encoder import Encoder, geometry_query, ipc_close, ipc_export, ipc_open
 
-DEPTH = 3          # images in flight per rank in DevicePipeline
+DEPTH = 4          # images in flight per rank in DevicePipeline (a put takes longer than a rank's share of the kernels)
 
 
 def partition_mcu_rows(mcu_rows, world, rank, rows_per_unit=1):
@@ -74,13 +78,13 @@ class HipStripEncoder:
         self.enc.entropy_sizes(slot.data_ptr(), stream)
 
     def place(self, target, sizes, rank, world, stream=0):
-        ptr, cap = target if rank else (0, 0)       # rank 0 assembles in its own buffer
+        ptr, cap = target if target is not None else (0, 0)       # None: this rank is the root and assembles in its own buffer
         self.enc.place(ptr, cap, sizes.data_ptr(), rank, world, stream)
 
     def file(self, target, sizes, rank, world):
         r = self.enc.sharded_result(sizes.data_ptr(), rank, world)
         self.last_result = r
-        return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device) if rank == 0 else None
+        return self._view(r["d_buffer"] + r["header_offset"], r["file_bytes"], self.d_img.device) if target is None else None
 
     # ---- host-synchronised protocol (encode_step / StripPipeline) ----
     def entropy(self, stream=0):
@@ -152,25 +156,34 @@ class DevicePipeline:
         slot k = i % DEPTH, on stream S_k and communicator G_k:
           transform(i) -> all_reduce(statistics) -> entropy_sizes(i) -> all_gather(sizes) -> place(i)
 
-    `place` compacts the strip locally and, on ranks > 0, puts it into rank 0's buffer of slot k at the offset a kernel
-    derives from the gathered sizes. One communicator per slot: collectives of different images then do not queue behind
-    each other (on one communicator the next image's all-reduce would wait for this image's all-gather, which waits for
-    this image's entropy coder). Every rank issues the same collectives in the same order.
+    Image i is assembled on its ROOT, rank i % (number of ranks that own a strip) -- rank 0 always with rotate=False. `place`
+    on the root compacts the strip straight to its place in the root's own buffer of slot k; on every other rank it compacts
+    locally and puts the strip into that buffer at the offset a kernel derives from the gathered sizes. One communicator per
+    slot: collectives of different images then do not queue behind each other (on one communicator the next image's
+    all-reduce would wait for this image's all-gather, which waits for this image's entropy coder). Every rank issues the
+    same collectives in the same order.
 
     Hazards, all resolved by stream order: a handle (coefficients, scratch, output buffer) is reused by image i + DEPTH on
-    the same stream; a peer's put of image i + DEPTH into rank 0's buffer k can only start after the all-gather of that
-    image, i.e. after rank 0 has enqueued everything of image i on S_k. The file of image i is complete on rank 0 once a
-    LATER collective of slot k has completed there (each peer enqueues it behind its put) -- `collect` issues one.
+    the same stream; a peer's put of image i + DEPTH into a root's buffer k can only start after the all-gather of that
+    image, i.e. after that root has executed everything of image i on its S_k -- including, when it was not image i's root,
+    its own put out of that buffer. The file of image i is complete on its root once a LATER collective of slot k has
+    completed there (each peer enqueues it behind its put) -- `collect` issues one.
 
     `strips` holds DEPTH strip encoders, or None on a rank that owns no strip (more ranks than restart-aligned strips):
-    such a rank contributes zero statistics and a zero size. `targets[k]` is what `place` / `file` take for slot k
-    (`open_file_targets` for the HIP encoder). An empty rank is never rank 0 (partition_mcu_rows).
+    such a rank contributes zero statistics and a zero size and is never a root (empty ranks come last, partition_mcu_rows).
+    `targets[k][r]` is what `place` / `file` take for slot k when rank r is the root: None on r itself
+    (`open_file_targets` for the HIP encoder).
     """
 
-    def __init__(self, torch, dist, strips, targets, optimize, device=None, use_streams=None):
+    def __init__(self, torch, dist, strips, targets, optimize, device=None, use_streams=None, rotate=True):
         self.torch, self.dist, self.strips, self.targets, self.optimize = torch, dist, strips, targets, optimize
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.depth = len(targets)
+        has = [None] * self.world
+        dist.all_gather_object(has, strips is not None)
+        self.nroots = sum(1 for h in has if h) if rotate else 1     # ranks 0 .. nroots-1 own strips
+        self.roots = [0] * self.depth                              # root of the image in each slot
+        self.last_root = 0
         if device is None:
             device = next((s.d_img.device for s in (strips or []) if s is not None and getattr(s, "d_img", None) is not None), torch.device("cpu"))
         self.device = device
@@ -205,6 +218,7 @@ class DevicePipeline:
         two). An older image still uncollected in that slot is overwritten: its file stays valid only until the peers' puts of
         the new image start, so callers that want EVERY file call `collect` before the slot comes round again."""
         k = self.i % self.depth
+        root = self.roots[k] = self.last_root = self.i % self.nroots
         self.pending = [q for q in self.pending if q != k]
         self.i += 1
         st = self.strips[k] if self.strips else None
@@ -217,14 +231,15 @@ class DevicePipeline:
                 st.entropy_sizes(self.mine[k], sh)
             self._all_gather(self.sizes[k], self.mine[k], self.groups[k])
             if st is not None:
-                st.place(self.targets[k], self.sizes[k], self.rank, self.world, sh)
+                st.place(self.targets[k][root], self.sizes[k], self.rank, self.world, sh)
         self.pending.append(k)
         return k
 
     def collect(self, want_file=True):
         """Complete the OLDEST pending image: one small collective behind every rank's put, a wait for this rank's stream,
-        then (rank 0, if wanted) the assembled file. Every rank must call this the same number of times, in the same order
-        relative to `step`. Not part of a steady-state step: the bench only flushes at the end of the timed region."""
+        then (on the image's root, if wanted) the assembled file; None on every other rank. Every rank must call this the same
+        number of times, in the same order relative to `step`. Not part of a steady-state step: the bench only flushes at the
+        end of the timed region."""
         if not self.pending:
             return None
         k = self.pending.pop(0)
@@ -235,11 +250,11 @@ class DevicePipeline:
         st = self.strips[k] if self.strips else None
         if st is None:
             return None
-        out = st.file(self.targets[k], self.sizes[k], self.rank, self.world)   # also checks this handle's status
-        return out if (want_file and self.rank == 0) else None
+        out = st.file(self.targets[k][self.roots[k]], self.sizes[k], self.rank, self.world)   # also checks this handle's status
+        return out if (want_file and self.rank == self.roots[k]) else None
 
     def flush(self):
-        """Complete everything in flight; returns (rank 0) the file of the LAST image issued."""
+        """Complete everything in flight; returns (on rank `last_root`) the file of the LAST image issued."""
         out = None
         while self.pending:
             out = self.collect(want_file=len(self.pending) == 1)
@@ -255,44 +270,48 @@ def full_scan_capacity(geometry):
     return geometry["mcus_per_row"] * geometry["mcu_rows"] * geometry["blocks_per_mcu"] * 64 + 65536
 
 
-def open_file_targets(torch, dist, strips, rank, world, device_index, whole_geometry):
-    """Peer mapping of rank 0's DEPTH output buffers on every other rank (mij_ipc_export / mij_ipc_open). Returns the list
-    of per-slot targets for DevicePipeline, or None when ANY rank could not map (then every rank takes the send/recv
-    fallback). Rank 0 first reserves room for the whole file in each of its handles."""
+def open_file_targets(torch, dist, strips, rank, world, device_index, whole_geometry, depth=None):
+    """Peer mapping of the output buffers of every rank that owns a strip -- any of them can be an image's root -- on every
+    other rank (mij_ipc_export / mij_ipc_open). Returns targets[k][r] = (pointer, capacity) of rank r's scan area of slot k as
+    this rank sees it (None for r = this rank, and for ranks without a strip), or None when ANY rank could not map (then every
+    rank takes the send/recv fallback). Every strip-owning rank first reserves room for the whole file in each of its handles."""
     cap = full_scan_capacity(whole_geometry)
-    payload, ok, targets = [None], True, None
-    if rank == 0:
+    mine, ok = None, True
+    if strips is not None:
         try:
-            handles = []
+            mine = []
             for st in strips:
                 st.enc.reserve_output(cap)
                 base, off, c = st.enc.output_buffer()
-                handles.append((ipc_export(base), off, c))
-            payload = [handles]
+                mine.append((ipc_export(base), off, c))
         except Exception as e:       # noqa: BLE001 -- any failure means "no peer mapping": all ranks fall back together
-            payload, ok = [("error", str(e))], False
-    dist.broadcast_object_list(payload, src=0)
-    handles = payload[0]
-    if isinstance(handles, tuple) and handles and handles[0] == "error":
+            mine, ok = ("error", str(e)), False
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    if any(isinstance(h, tuple) and h and h[0] == "error" for h in every):
         ok = False
-    elif rank == 0:
-        targets = [(0, 0)] * len(handles)
-    else:
+    nslots = depth if depth is not None else max((len(h) for h in every if isinstance(h, list)), default=0)
+    targets = [[None] * world for _ in range(nslots)]
+    opened = []
+    if ok:
         try:
-            targets = []
-            for h, off, c in handles:
-                targets.append((ipc_open(device_index, h) + off, c))
+            for r, handles in enumerate(every):
+                if r == rank or not isinstance(handles, list):
+                    continue
+                for k, (h, off, c) in enumerate(handles):
+                    p = ipc_open(device_index, h)
+                    opened.append(p)
+                    targets[k][r] = (p + off, c)
         except Exception:            # noqa: BLE001
             ok = False
     oks = [None] * world
     dist.all_gather_object(oks, bool(ok))
     if not all(oks):
-        if targets and rank:
-            for p, _ in targets:
-                try:
-                    ipc_close(p)
-                except Exception:    # noqa: BLE001
-                    pass
+        for p in opened:
+            try:
+                ipc_close(p)
+            except Exception:        # noqa: BLE001
+                pass
         return None
     return targets
 

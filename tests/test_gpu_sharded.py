@@ -92,10 +92,10 @@ def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_eac
     last = pipe.flush()
     if not collect_each:
         outs = [None] * (nimg - 1) + [None if last is None else last.cpu().numpy().tobytes()]
+    for i, o in enumerate(outs):          # a file comes out on its image's root (the roots rotate over the ranks with a strip)
+        if o is not None:
+            open(out_path + ".%d" % i, "wb").write(o)
     if rank == 0:
-        for i, o in enumerate(outs):
-            if o is not None:
-                open(out_path + ".%d" % i, "wb").write(o)
         open(out_path + ".ri", "w").write(str(whole["restart_interval"]))
     dist.barrier()
     for e in encs:
@@ -161,8 +161,8 @@ def test_hip_strips_five_ranks_uneven(oracle, tmp_path):
 @pytest.mark.parametrize("pipeline", ["put", "sendrecv", None])
 def test_bench_multi_rank_rehearsal(tmp_path, pipeline):
     """bench.py's N > 1 path end to end (launcher, strips, collectives, gather, the JSON line), rehearsed with three ranks
-    on the one GPU over gloo: the file must be the single-GPU file. All three forms of the step: three images in flight
-    with the put gather (sharded.DevicePipeline, the default), two in flight with send/recv (sharded.StripPipeline, the
+    on the one GPU over gloo: the file must be the single-GPU file. All three forms of the step: four images in flight
+    with the put gather and a rotating root (sharded.DevicePipeline, the default), two in flight with send/recv (sharded.StripPipeline, the
     fallback) and one at a time (sharded.encode_step)."""
     import json
     import subprocess
@@ -177,7 +177,7 @@ def test_bench_multi_rank_rehearsal(tmp_path, pipeline):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 3 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == {"put": 3, "sendrecv": 2, None: 1}[pipeline]
+    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == {"put": 4, "sendrecv": 2, None: 1}[pipeline]
     assert d["config"]["gather"] == (pipeline or "sendrecv")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--no-psnr", "--height", "4000"], capture_output=True, text=True, timeout=600, cwd=ROOT)

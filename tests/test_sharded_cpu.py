@@ -51,20 +51,26 @@ class OracleStripEncoder:
     def collect_strip(self):
         return self.entropy()
 
-    # ---- device-side protocol (sharded.DevicePipeline); `target` = rank 0's scan area, a shared-memory uint8 tensor ----
+    # ---- device-side protocol (sharded.DevicePipeline); `target` = the root's buffer (shared-memory tensors play the peer
+    # mapping), None on the root itself, which then uses `self.own`. The oracle writes a header only with the first strip, so
+    # here the rank that owns it drops the header into the root's buffer (the HIP encoder builds it on every rank).
     def entropy_sizes(self, slot, stream=0):
         self._hdr, self._scan = self.entropy()
         slot[0] = self._scan.numel()
 
     def place(self, target, sizes, rank, world, stream=0):
+        buf = self.own if target is None else target
         off = int(sizes[:rank].sum())
         assert int(sizes[rank]) == self._scan.numel()
-        target[off:off + self._scan.numel()] = self._scan
+        buf["scan"][off:off + self._scan.numel()] = self._scan
+        if self.r0 == 0:
+            buf["hdr"][:self._hdr.numel()] = self._hdr
+            buf["hl"][0] = self._hdr.numel()
 
     def file(self, target, sizes, rank, world):
-        if rank != 0:
+        if target is not None:
             return None
-        return torch.cat([self._hdr, target[:int(sizes.sum())]])
+        return torch.cat([self.own["hdr"][:int(self.own["hl"][0])], self.own["scan"][:int(sizes.sum())]])
 
 
 def _pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, out_path):
@@ -119,7 +125,7 @@ def _worker(rank, world, port, W, H, css, optimize, ri, q, out_path):
     dist.destroy_process_group()
 
 
-def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, collect_each, targets, out_path):
+def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, collect_each, targets, out_path, rotate):
     """DevicePipeline: `nimg` different images; either every file is collected before its slot comes round again
     (collect_each) or the loop runs like the bench -- issue only, one flush at the end, which yields the LAST file."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -134,7 +140,11 @@ def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg,
     depth = len(targets)
     encs = [OracleStripEncoder(O, None, W, H, q, css, optimize, ri, r0, r1, geo) for _ in range(depth)] if r1 > r0 else None
     assert rank != 0 or encs is not None              # rank 0 always owns the first strip
-    pipe = sharded.DevicePipeline(torch, dist, encs, targets, optimize, device=torch.device("cpu"))
+    if encs is not None:
+        for k, e in enumerate(encs):
+            e.own = targets[k][rank]
+    mine = [[None if r == rank else t for r, t in enumerate(row)] for row in targets]      # what open_file_targets returns
+    pipe = sharded.DevicePipeline(torch, dist, encs, mine, optimize, device=torch.device("cpu"), rotate=rotate)
     outs = []
     for i in range(nimg):
         if encs is not None:
@@ -146,35 +156,37 @@ def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg,
     last = pipe.flush()
     if not collect_each:
         outs = [None] * (nimg - 1) + [None if last is None else last.clone()]
-    if rank == 0:
-        for i, o in enumerate(outs):
-            if o is not None:
-                open(out_path + ".%d" % i, "wb").write(o.numpy().tobytes())
-    else:
-        assert all(o is None for o in outs)
+    for i, o in enumerate(outs):          # a file comes out on its image's root: rank i % (ranks with a strip), or rank 0
+        if o is not None:
+            assert rotate or rank == 0
+            open(out_path + ".%d" % i, "wb").write(o.numpy().tobytes())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _shared_targets(depth, nbytes):
-    return [torch.zeros(nbytes, dtype=torch.uint8).share_memory_() for _ in range(depth)]
+def _shared_targets(depth, world, nbytes):
+    """targets[k][r]: rank r's buffer of slot k -- scan area, header area, header length -- visible to every process"""
+    return [[{"scan": torch.zeros(nbytes, dtype=torch.uint8).share_memory_(), "hdr": torch.zeros(4096, dtype=torch.uint8).share_memory_(),
+              "hl": torch.zeros(1, dtype=torch.int64).share_memory_()} for _ in range(world)] for _ in range(depth)]
 
 
-@pytest.mark.parametrize("world,css,optimize,ri,collect_each", [
-    (2, 1, True, 13, True), (3, 1, True, 13, True), (5, 2, True, 26, True), (8, 1, True, 13, True), (8, 0, False, 13, True),
-    (2, 1, True, 40, True),        # one restart-aligned strip only: rank 1 owns nothing (the case round 1 dropped)
-    (8, 1, True, 26, True),        # interval spans 2 MCU rows: 16 units over 8 ranks
-    (8, 2, True, 104, True),       # 13 MCUs per row, 16 rows, interval 104 = 8 rows: 2 units, six empty ranks
-    (3, 1, True, 13, False), (8, 1, True, 13, False),
+@pytest.mark.parametrize("world,css,optimize,ri,collect_each,rotate", [
+    (2, 1, True, 13, True, True), (3, 1, True, 13, True, True), (5, 2, True, 26, True, True), (8, 1, True, 13, True, True), (8, 0, False, 13, True, True),
+    (2, 1, True, 40, True, True),        # one restart-aligned strip only: rank 1 owns nothing (the case round 1 dropped)
+    (8, 1, True, 26, True, True),        # interval spans 2 MCU rows: 16 units over 8 ranks
+    (8, 2, True, 104, True, True),       # 13 MCUs per row, 16 rows, interval 104 = 8 rows: 2 units, six empty ranks: two roots
+    (3, 1, True, 13, False, True), (8, 1, True, 13, False, True),
+    (3, 1, True, 13, True, False), (8, 1, True, 13, False, False),      # the fixed root (rank 0 assembles every file)
 ])
-def test_device_pipeline_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri, collect_each):
-    """DEPTH images in flight, sizes all-gathered device-to-device, strips put at offsets derived from them: every image must
-    come out as the 1-rank file (collect_each), and a bench-style loop (issue only, flush once) must end on the last one."""
+def test_device_pipeline_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri, collect_each, rotate):
+    """DEPTH images in flight, sizes all-gathered device-to-device, strips put at offsets derived from them, the assembling
+    rank rotating from image to image: every image must come out as the 1-rank file (collect_each), and a bench-style loop
+    (issue only, flush once) must end on the last one."""
     from nvjpeg_imagecompressor_amd import sharded
-    W, H, q, nimg = 208, 250, 92, 7
+    W, H, q, nimg = 208, 250, 92, 9
     out = str(tmp_path / "dev.jpg")
-    targets = _shared_targets(sharded.DEPTH, 3 * W * (H + 16))
-    mp.spawn(_device_pipeline_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, nimg, collect_each, targets, out),
+    targets = _shared_targets(sharded.DEPTH, world, 3 * W * (H + 16))
+    mp.spawn(_device_pipeline_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, nimg, collect_each, targets, out, rotate),
              nprocs=world, join=True)
     for i in (range(nimg) if collect_each else [nimg - 1]):
         want = oracle.encode(np.roll(oracle.synth_rgb(W, H), 7 * i, axis=1).copy(), q, css, optimize, ri)

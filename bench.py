@@ -8,7 +8,7 @@ A "step" is one whole encode of the image. At N > 1 the image is cut into restar
 rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
 of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes (device to device), and every
 rank > 0 PUTS its strip into the file rank 0 assembles (peer-mapped buffer, one xGMI link per rank) at the offset a
-kernel derives from the gathered sizes; three images in flight per rank, no host wait in a step (sharded.DevicePipeline;
+kernel derives from the gathered sizes; four images in flight per rank, no host wait in a step (sharded.DevicePipeline;
 RCCL send/recv with host-side sizes if the peer mapping is unavailable). Total work is fixed as N grows => "scaling":
 "strong".  Rank 0 prints ONE JSON line.
 """
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=1000, help="rows per CPU-baseline strip (one strip per core)")
     ap.add_argument("--cpu-one-core-rows", type=int, default=0, help="rows of the 1-core CPU sample (0 = the whole image, SURVEY 8d (i))")
     ap.add_argument("--gather", default=os.environ.get("MIJ_SHARDED_GATHER", "put"), choices=["put", "sendrecv"],
-                    help="N > 1: put = strips written into rank 0's peer-mapped buffer, sizes stay on the device (default); "
+                    help="N > 1: put = strips written into the assembling rank's peer-mapped buffer, sizes stay on the device (default); "
                          "sendrecv = host-side sizes + RCCL send/recv (also the automatic fallback)")
     return ap.parse_args()
 
@@ -150,8 +150,8 @@ def main():
 
     # Images in flight. Every step still produces a complete file inside the timed region.
     #  * One GPU: two handles alternate; what disappears is the GPU idling during the host's round trip for the result.
-    #  * N GPUs, "put" (sharded.DevicePipeline): three images in flight, sizes all-gathered device to device, strips written
-    #    straight into rank 0's peer-mapped buffer; no host wait inside a step. If the buffers cannot be mapped, or with
+    #  * N GPUs, "put" (sharded.DevicePipeline): four images in flight, sizes all-gathered device to device, strips written
+    #    straight into the peer-mapped buffer of the image's root (which rotates over the ranks); no host wait inside a step. If the buffers cannot be mapped, or with
     #    --gather sendrecv: sharded.StripPipeline (two in flight, sizes via the host, RCCL send/recv).
     #    MIJ_BENCH_NO_PIPELINE=1: one image at a time (sharded.encode_step).
     pipelined = n_handles > 1

@@ -7,7 +7,8 @@ Huffman (reference README.md:48 config), device-resident input -> device-residen
 A "step" is one whole encode of the image. At N > 1 the image is cut into restart-interval-aligned strips of MCU
 rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
 of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes (device to device), and every
-rank > 0 PUTS its strip into the file rank 0 assembles (peer-mapped buffer, one xGMI link per rank) at the offset a
+rank PUTS its strip into the file the image's root assembles (peer-mapped buffer, one xGMI link per rank; the root rotates
+over the ranks from image to image, so no GPU's inbound links carry every file) at the offset a
 kernel derives from the gathered sizes; four images in flight per rank, no host wait in a step (sharded.DevicePipeline;
 RCCL send/recv with host-side sizes if the peer mapping is unavailable). Total work is fixed as N grows => "scaling":
 "strong".  Rank 0 prints ONE JSON line.

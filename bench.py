@@ -142,7 +142,7 @@ def main():
     if enc is not None:
         d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
         mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
-        strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt) for e in encs]
+        strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=world > 1) for e in encs]
     strip = strips[0]
     torch.cuda.synchronize()
 

@@ -63,11 +63,14 @@ def rows_per_restart_unit(mcus_per_row, restart_interval):
 class HipStripEncoder:
     """Strip encoder backed by libmijpeg (HIP). `d_img` is this rank's strip of the image, device resident."""
 
-    def __init__(self, torch, enc, d_img, fmt="bgr"):
+    def __init__(self, torch, enc, d_img, fmt="bgr", shared_statistics=True):
         self.torch, self.enc, self.d_img, self.fmt = torch, enc, d_img, fmt
         self.pitch = d_img.stride(0) * d_img.element_size()
         self.d_hist = torch.zeros(4 * 257, dtype=torch.int32, device=d_img.device)
-        enc.set_histogram_buffer(self.d_hist.data_ptr())
+        # The statistics go to a tensor a collective can reduce in place. A single rank has nothing to reduce and leaves the
+        # handle on its own buffers (shared_statistics=False): those alternate and need no clearing per image.
+        if shared_statistics:
+            enc.set_histogram_buffer(self.d_hist.data_ptr())
 
     def transform(self, stream=0):
         self.enc.transform(self.d_img.data_ptr(), self.pitch, self.fmt, 0, stream)

@@ -36,6 +36,8 @@ struct mij_encoder {
     uint32_t *seg_bytes = nullptr, *seg_ff = nullptr, *hist = nullptr, *ovf = nullptr;
     uint8_t *flag = nullptr;          // per interval: 1 = the lane-per-block coder left it to the serial kernel
     bool fast = false;                // scan coded by k_encode_prog2.inc
+    bool narrow = false;              // refinement scan: emit with 16-word strips (dropped when too many intervals overflow them)
+    uint32_t seen_recoded = 0;
     int stream_index = 0;
     unsigned long long *seg_off = nullptr, *chunk_total = nullptr, *chunk_base = nullptr;
     DeviceTables *tab = nullptr;
@@ -338,6 +340,9 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
       o_so[i] = take((size_t)q.nseg * 8); o_ct[i] = take(nch * 8); o_cb[i] = take(nch * 8); o_h[i] = take(4 * 257 * 4);
       o_t[i] = take(sizeof(DeviceTables)); o_r[i] = take(sizeof(DeviceResult)); o_v[i] = take(4); o_f[i] = take((size_t)q.nseg);
       q.fast = prog2_supported(sd) && getenv("MIJ_PROG_SERIAL") == nullptr;   // A/B switch: the lane-per-interval kernel only
+      // first guess; the count of overflowed intervals corrects it after the first image (the last luma refinement of a
+      // high-quality file has blocks of more than 512 bits: q95 synthetic, a third of its intervals)
+      q.narrow = q.fast && sd.kind == 4 && (sd.comp[0] != 0 || sd.Al > 0 || p->quality <= 85) && getenv("MIJ_PROG_WIDE") == nullptr;
     }
     CRCHK(hipMalloc(&e->d_prog, total));
     for (int i = 0; i < 10; i++) {
@@ -349,6 +354,7 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
       q.flag = e->d_prog + o_f[i];
       CRCHK(hipMemset(q.flag, 0, (size_t)q.nseg));
       CRCHK(hipMemset(q.ovf, 0, 4));
+      CRCHK(hipMemset(q.res, 0, sizeof(DeviceResult)));
     }
     CRCHK(hipHostMalloc(&e->h_prog_tab, 10 * sizeof(DeviceTables), hipHostMallocDefault));
     CRCHK(hipHostMalloc(&e->h_prog_res, 10 * sizeof(DeviceResult), hipHostMallocDefault));
@@ -529,7 +535,7 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
       HIPCHK(e, hipMemsetAsync(q.hist, 0, 4 * 257 * sizeof(uint32_t), st));
       // (K3 builds all four tables; the ones this scan does not use get a single count so that they are well formed:
       //  the lane-per-block gather kernels write it themselves, the serial one gets it by copy)
-      if (q.fast) HIPCHK(e, launch_prog2(g, q.sd, 1, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st));
+      if (q.fast) HIPCHK(e, launch_prog2(g, q.sd, 1, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st, false, nullptr));
       else {
         HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
         for (int w = 0; w < 4; w++) {
@@ -543,13 +549,19 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
     }
     if (q.fast) {
       // lane per block; intervals it hands back (forced flushes of jcphuff.c, oversized blocks) go through the serial kernel
-      HIPCHK(e, launch_prog2(g, q.sd, 0, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st));
+      HIPCHK(e, launch_prog2(g, q.sd, 0, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st, q.narrow, q.res));
       if (q.sd.kind >= 3) HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st, q.flag));
     } else HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
     HIPCHK(e, launch_scan(q.seg_bytes, q.seg_ff, q.seg_off, q.nseg, q.chunk_total, q.chunk_base, q.ovf, q.res, st));
     HIPCHK(e, hipMemcpyAsync(&e->h_prog_res[i], q.res, sizeof(DeviceResult), hipMemcpyDeviceToHost, st));
   }
   for (auto &st : e->prog_stream) HIPCHK(e, hipStreamSynchronize(st));
+  for (int i = 0; i < 10; i++) {        // as note_recoded for K4: more than 1 % of the intervals re-coded -> wide strips from now on
+    mij_encoder::ProgScan &q = e->ps[i];
+    const uint32_t d = e->h_prog_res[i].recoded - q.seen_recoded;
+    q.seen_recoded = e->h_prog_res[i].recoded;
+    if (q.narrow && (long long)d * 100 > q.nseg) q.narrow = false;
+  }
 
   // ---- headers and offsets (jcmarker.c: frame header; per scan DHT of the tables it uses, DRI before the first SOS, SOS)
   std::vector<uint8_t> hdr[10];

@@ -167,10 +167,11 @@ hipError_t launch_prog_encode(const Geom &g, const ScanDesc &sd, int gather, con
                               size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, long long nseg, hipStream_t s,
                               const uint8_t *only_flagged = nullptr);
 // Lane-per-block form (k_encode_prog2.inc); seg_flag[interval] = 1 where the emit pass left an interval to the serial kernel.
+// narrow (refinement scans, emit pass): 16-word strips, five waves per SIMD; overflowed intervals are counted in res->recoded.
 bool prog2_supported(const ScanDesc &sd);
 hipError_t launch_prog2(const Geom &g, const ScanDesc &sd, int gather, const int16_t *coef, const int16_t *dc, const DeviceTables *tab,
                         uint8_t *scratch, size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, uint8_t *seg_flag,
-                        long long nseg, hipStream_t s);
+                        long long nseg, hipStream_t s, bool narrow, DeviceResult *res);
 // Parallel (self-synchronising) decode of a baseline interleaved scan. `ws` is a workspace of par_workspace_bytes().
 size_t par_workspace_bytes(size_t scan_len, long long nseg);
 // The decoder reads an un-stuffed copy of the scan without its restart markers: launch_clean_scan makes it (clean: capacity >=

@@ -112,3 +112,19 @@ def test_progressive_output_larger_than_the_preallocated_buffer(mij, oracle):
     assert len(got) > (W // 8) * (H // 8) * 3 * 64 + 65536      # really beyond the initial capacity (2 B per coefficient)
     dec = np.asarray(Image.open(io.BytesIO(got)).convert("RGB"))
     assert dec.shape == img.shape
+
+
+@pytest.mark.parametrize("q", [95, 85, 60])
+def test_refinement_scans_with_narrow_strips_and_after_the_switch_to_wide(mij, oracle, q):
+    """The emit pass of a refinement scan starts on 16-word strips; blocks that overflow them go to the serial kernel, and
+    a scan that overflows often is coded with 24-word strips from the next image on: both files must be the oracle's."""
+    W, H = 1536, 1024
+    rng = np.random.default_rng(q)
+    noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    busy = oracle.synth_rgb(W, H)
+    busy[::2, 1::2] ^= 0x3F                                        # fine texture on the synthetic image
+    for css in (1, 0):
+        with mij.Encoder(W, H, q, True, css, progressive=True) as enc:
+            ri = enc.geometry["restart_interval"]
+            for img in (noise, noise, busy, noise):
+                assert enc.encode_host(img, "rgb") == oracle.encode_progressive(img, q, css, ri)

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmijpeg.so")
 STAMP = LIB + ".srchash"
-SOURCES = ["mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip", "mij_peer.hip"]
+SOURCES = ["mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 

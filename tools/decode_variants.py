@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Builds libmijpeg.so with other compile-time settings of the parallel Huffman decoder (k_decode_par.inc) and, with `run`,
+times the full-size decode with each (tools/decode_fullsize.py).  Usage:
+    python tools/decode_variants.py build          (here, no GPU needed)
+    python tools/decode_variants.py run            (on the GPU box)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "variants")
+VARIANTS = {"dec_default": {}, "dec_s512": {"MIJ_PAR_S": 512}, "dec_s2048": {"MIJ_PAR_S": 2048}, "dec_s768": {"MIJ_PAR_S": 768}}
+if os.environ.get("MIJ_VARIANTS"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
+
+
+def build():
+    for name, defs in VARIANTS.items():
+        d = os.path.join(OUT, name)
+        os.makedirs(d, exist_ok=True)
+        objs = []
+        for src in ("mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip"):
+            obj = os.path.join(d, src.replace(".hip", ".o"))
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DMIJ_FAST_BUILD"] + [
+                "-D%s=%s" % kv for kv in defs.items()] + ["-c", os.path.join(CSRC, src), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode:
+                print(r.stderr[-2000:])
+                raise SystemExit(1)
+            objs.append(obj)
+        subprocess.check_call(["g++", "-shared", "-o", os.path.join(d, "libmijpeg.so")] + objs)
+        print("built", name, flush=True)
+
+
+def run():
+    for name in VARIANTS:
+        env = dict(os.environ, MIJ_LIB_PATH=os.path.join(OUT, name, "libmijpeg.so"))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decode_fullsize.py")], capture_output=True, text=True, env=env)
+        print(name, r.stdout.strip()[-400:] if r.returncode == 0 else "FAILED " + r.stderr[-600:], flush=True)
+
+
+if __name__ == "__main__":
+    build() if sys.argv[1] == "build" else run()

@@ -52,10 +52,14 @@ def _noise_image(W, rows):
     return full
 
 
-def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path, noise=False):
+def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path, noise=False, backend="gloo"):
     """sharded.DevicePipeline on real HIP handles: DEPTH images in flight, peer-mapped rank-0 buffers, k_put."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":       # RCCL, initialised the way bench.py does it (one rank: RCCL refuses two ranks on one device)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import nvjpeg_imagecompressor_amd as mij
     from nvjpeg_imagecompressor_amd import sharded
     torch.cuda.set_device(0)
@@ -124,6 +128,26 @@ def test_device_pipeline_put_gather(oracle, tmp_path, world, css, optimize, ri, 
         want = oracle.encode(np.ascontiguousarray(full[8 * i:8 * i + H]), 95, css, optimize, dri)
         got = open(out + ".%d" % i, "rb").read()
         assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want), i
+
+
+def test_device_pipeline_over_rccl_single_rank(oracle, tmp_path):
+    """The one thing a one-GPU box can show about the measured configuration: the pipeline's calls as RCCL takes them -- the
+    eager communicator, four split communicators, the int32 statistics all-reduce on a handle's own memory, the int64 sizes
+    all-gather, stream order between the library's kernels and RCCL's -- with a single rank (its own root), five images,
+    four in flight, files against the oracle."""
+    import numpy as np
+    W, H, nimg = 2080, 1000, 6
+    out = str(tmp_path / "rccl.jpg")
+    mp.spawn(_device_worker, args=(1, _free_port(), W, H, 1, True, -1, nimg, False, out, False, "nccl"), nprocs=1, join=True)
+    dri = int(open(out + ".ri").read())
+    full = oracle.synth_rgb(W, H + 8 * nimg)
+    want = oracle.encode(np.ascontiguousarray(full[8 * (nimg - 1):8 * (nimg - 1) + H]), 95, 1, True, dri)
+    assert open(out + ".%d" % (nimg - 1), "rb").read() == want
+    out2 = str(tmp_path / "rccl_each.jpg")
+    mp.spawn(_device_worker, args=(1, _free_port(), W, H, 2, True, -1, 3, True, out2, False, "nccl"), nprocs=1, join=True)
+    for i in range(3):
+        want = oracle.encode(np.ascontiguousarray(full[8 * i:8 * i + H]), 95, 2, True, int(open(out2 + ".ri").read()))
+        assert open(out2 + ".%d" % i, "rb").read() == want, i
 
 
 def _free_port():

@@ -378,6 +378,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   else DHIP(d, hipMemcpyAsync(d->d_scan, jpeg + data_off, scan_len, hipMemcpyHostToDevice, s));
   DHIP(d, hipMemsetAsync(d->d_flags, 0, 2 * sizeof(uint32_t), s));
   const DecTables *d_final = d->d_tab;
+  DcFix dc_fix{};                          // set by the parallel route: the IDCT completes the DC terms
   if (ps.fast) {
     DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
     DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
@@ -395,8 +396,9 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
       DHIP(d, launch_clean_scan(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_clean, d->d_clean_len, d->d_flags,
                                 d->d_res, s));
       DHIP(d, launch_par_decode(g, d->d_clean, scan_len, d->d_clean_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_par_ws, d->d_flags + 2,
-                                d->d_flags + 1, &d->sync_passes, s));
-      if (d->sync_passes < 0) {  // the states did not settle within 64 passes (adversarial data): exact lane-per-interval decode of the raw stream
+                                d->d_flags + 1, &d->sync_passes, s, &dc_fix));
+      if (d->sync_passes < 0) {
+        dc_fix = DcFix{};  // the states did not settle within 64 passes (adversarial data): exact lane-per-interval decode of the raw stream
         DHIP(d, launch_find_restarts(scan_dev, scan_len, d->d_chunk_cnt, d->d_chunk_base, d->d_seg_pos, max_seg, d->d_flags, d->d_res, s));
         DHIP(d, launch_huff_decode(g, scan_dev, scan_len, d->d_seg_pos, max_seg, d->d_tab, d->d_coef, d->d_flags + 1, s));
       }
@@ -474,7 +476,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     d_final = d->d_tabs + (ps.scans.size() - 1);
   }
   uint8_t *py = d->d_planes, *pcb = py + ysz, *pcr = pcb + csz;
-  DHIP(d, launch_idct(g, d->d_coef, d_final, py, pcb, pcr, s));
+  DHIP(d, launch_idct(g, d->d_coef, d_final, py, pcb, pcr, s, dc_fix));
   DHIP(d, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, pitch, plane_stride, output_format, s));
   DHIP(d, hipEventRecord(d->ev1, s));
   d->issued = true;

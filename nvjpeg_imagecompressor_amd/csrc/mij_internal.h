@@ -178,10 +178,19 @@ size_t par_workspace_bytes(size_t scan_len, long long nseg);
 // n + 64; cnt / base: 2 x (n / 16384 + 1) words each) together with the intervals' start positions in it.
 hipError_t launch_clean_scan(const uint8_t *scan, size_t n, unsigned long long *cnt, unsigned long long *base, unsigned long long *seg_pos,
                              long long nseg, uint8_t *clean, unsigned long long *clean_len, uint32_t *flag, DeviceResult *res, hipStream_t s);
+// The parallel decoder leaves every DC term as the sum of the differences since the start of ITS SUBSEQUENCE; what is missing
+// -- the sum over the earlier subsequences of the restart interval -- is in the scanned per-subsequence sums, which `fix`
+// describes (they live in `ws`): launch_idct adds it while it loads the block (DcFix::pref == nullptr: DC terms are final).
+struct DcFix {
+  const int4 *pref = nullptr;        // exclusive scan over the subsequences of (blocks begun, DC-difference sums Y, Cb, Cr)
+  const int4 *sub_pref = nullptr;    // exclusive scan over the restart intervals of their subsequence counts (.x)
+  uint32_t bpi = 0, bpi_magic = 0;   // blocks per restart interval, floor(2^32 / bpi)
+};
 hipError_t launch_par_decode(const Geom &g, const uint8_t *clean, size_t n, const unsigned long long *clean_len, const unsigned long long *seg_pos,
                              long long nseg, const DecTables *tab, int16_t *coef, void *ws, uint32_t *changed, uint32_t *err_flag, int *passes,
-                             hipStream_t s);
-hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
+                             hipStream_t s, DcFix *fix);
+hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s,
+                       const DcFix &fix = DcFix{});
 hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, uint8_t *dst, size_t pitch,
                                  size_t plane_stride, int out_fmt, hipStream_t s);
 hipError_t launch_residual(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int sign, hipStream_t s);

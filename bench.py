@@ -2,7 +2,16 @@
 """bench.py -- headline metric of BASELINE.json: Mpixels/s JPEG encode of 8320x40000 RGB8, q95, 4:2:2, optimised
 Huffman (reference README.md:48 config), device-resident input -> device-resident JFIF bitstream.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 launches ITSELF: the process started by the command line never touches a GPU; it starts N fresh child processes (one
+rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, RCCL between them), relays rank 0's JSON line
+and exits with their status. It watches them: if a rank dies or the run makes no progress within a bound, the children are
+killed (exactly the process groups it started) and FRESH ones are started with the next gather of the ladder
+put -> sendrecv -> serial; the line then carries "gather_fallback": "<reason>". Started under an external launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) local rank 0 becomes that supervisor and the
+launcher's other ranks leave at once, so both command shapes run the same children with the same safety net
+(MIJ_BENCH_DIRECT=1: be a plain rank of the external launcher instead, no supervisor).
 
 A "step" is one whole encode of the image. At N > 1 the image is cut into restart-interval-aligned strips of MCU
 rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
@@ -10,7 +19,7 @@ of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of str
 rank PUTS its strip into the file the image's root assembles (peer-mapped buffer, one xGMI link per rank; the root rotates
 over the ranks from image to image, so no GPU's inbound links carry every file) at the offset a
 kernel derives from the gathered sizes; four images in flight per rank, no host wait in a step (sharded.DevicePipeline;
-RCCL send/recv with host-side sizes if the peer mapping is unavailable). Total work is fixed as N grows => "scaling":
+RCCL send/recv with host-side sizes if the peer mapping is unavailable or the put pipeline fails). Total work is fixed as N grows => "scaling":
 "strong".  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -55,9 +64,15 @@ def parse():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1000, help="rows per CPU-baseline strip (one strip per core)")
     ap.add_argument("--cpu-one-core-rows", type=int, default=0, help="rows of the 1-core CPU sample (0 = the whole image, SURVEY 8d (i))")
-    ap.add_argument("--gather", default=os.environ.get("MIJ_SHARDED_GATHER", "put"), choices=["put", "sendrecv"],
+    ap.add_argument("--gather", default=os.environ.get("MIJ_SHARDED_GATHER", "put"), choices=["put", "sendrecv", "serial"],
                     help="N > 1: put = strips written into the assembling rank's peer-mapped buffer, sizes stay on the device (default); "
-                         "sendrecv = host-side sizes + RCCL send/recv (also the automatic fallback)")
+                         "sendrecv = host-side sizes + RCCL send/recv, two images in flight; serial = one image at a time. The supervisor "
+                         "falls back along put -> sendrecv -> serial with fresh processes when a run dies or stalls")
+    ap.add_argument("--comms", default="ordered", choices=["ordered", "per-slot"],
+                    help="N > 1, put gather: ordered = every collective on ONE communicator in one global order, an image's all-gather issued "
+                         "behind the next image's all-reduce (default); per-slot = one communicator per image slot (experiment: concurrent "
+                         "communicators are not ordered against each other across ranks)")
+    ap.add_argument("--no-fallback", action="store_true", help="N > 1: fail instead of retrying with the next gather of the ladder")
     return ap.parse_args()
 
 
@@ -97,8 +112,168 @@ def cpu_baselines(args, optimize, restart_interval):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+# =====================================================================================================================
+# Supervisor: the process of `python bench.py --gpus N` (N > 1). It never imports torch or touches a GPU.
+# =====================================================================================================================
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _child_argv(mode):
+    """This command line with the gather replaced by `mode`."""
+    out, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a == "--gather":
+            skip = True
+            continue
+        if a.startswith("--gather="):
+            continue
+        out.append(a)
+    return [sys.executable, os.path.abspath(__file__)] + out + ["--gather", mode]
+
+
+def _kill_children(procs):
+    """Ends exactly the processes this supervisor started (each child leads its own process group): TERM, then KILL."""
+    import signal
+    for sig, wait in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 10.0)):
+        alive = [p for p in procs if p.poll() is None]
+        if not alive:
+            return
+        for p in alive:
+            try:
+                os.killpg(p.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.monotonic() + wait
+        while time.monotonic() < t_end and any(p.poll() is None for p in alive):
+            time.sleep(0.1)
+
+
+def _run_attempt(world, mode):
+    """One set of fresh child ranks. Returns (json_line or None, failure reason or None, note)."""
+    import queue
+    import subprocess
+    import threading
+    init_bound = float(os.environ.get("MIJ_BENCH_WATCHDOG_INIT_S", "600"))     # first import of torch on a fresh box: minutes
+    step_bound = float(os.environ.get("MIJ_BENCH_WATCHDOG_S", "300"))          # between two progress marks afterwards
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k not in ("GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                                                                        "GROUP_WORLD_SIZE", "ROLE_NAME")}
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MIJ_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("MIJ_BENCH_NO_PIPELINE", None)
+        procs.append(subprocess.Popen(_child_argv(mode), env=env, cwd=ROOT, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else 2, text=(r == 0) or None))       # other ranks: stdout -> our stderr (fd 2)
+    lines = queue.Queue()
+
+    def pump():
+        for ln in procs[0].stdout:
+            lines.put(ln.rstrip("\n"))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    result, phase, last, reason = None, "start", time.monotonic(), None
+    while True:
+        try:
+            while True:
+                ln = lines.get(timeout=0.25)
+                if ln.startswith("##progress"):
+                    phase, last = ln[len("##progress"):].strip(), time.monotonic()
+                elif ln.startswith("{"):
+                    result, last = ln, time.monotonic()
+                elif ln:
+                    print(ln, file=sys.stderr, flush=True)
+        except queue.Empty:
+            pass
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and result is None:
+            reason = "rank %d exited with status %d after '%s'" % (bad[0][0], bad[0][1], phase)
+            break
+        if all(c is not None for c in codes):
+            if result is None:
+                reason = "all ranks exited without a result line (after '%s')" % phase
+            elif bad:          # measured, verified and reported by rank 0 with every rank taking part; a rank then failed on its way out
+                _kill_children(procs)
+                return result, None, "rank %d exited with status %d after the result line" % bad[0]
+            break
+        bound = init_bound if phase == "start" else step_bound
+        if time.monotonic() - last > bound:
+            if result is not None:       # measured and reported; a rank is stuck tearing down
+                _kill_children(procs)
+                return result, None, "ranks still alive %.0f s after the result line were ended by the supervisor" % bound
+            reason = "no progress for %.0f s after '%s'" % (bound, phase)
+            break
+    _kill_children(procs)
+    th.join(timeout=2.0)
+    return (result, None, None) if reason is None else (None, reason, None)
+
+
+def supervise(args, world, launcher):
+    ladder = {"put": ["put", "sendrecv", "serial"], "sendrecv": ["sendrecv", "serial"], "serial": ["serial"]}[args.gather]
+    if args.no_fallback or args.progressive:
+        ladder = ladder[:1]
+    failures = []
+    for mode in ladder:
+        line, reason, note = _run_attempt(world, mode)
+        if line is not None:
+            out = json.loads(line)
+            out["launcher"] = launcher
+            out["gather_fallback"] = "; ".join(failures) if failures else None
+            if note:
+                out["teardown_note"] = note
+            print(json.dumps(out), flush=True)
+            return 0
+        failures.append("%s: %s" % (mode, reason))
+        print("[bench] gather '%s' failed (%s)%s" % (mode, reason, "; starting fresh ranks with the next one" if mode != ladder[-1] else ""),
+              file=sys.stderr, flush=True)
+    print("[bench] every gather failed: " + "; ".join(failures), file=sys.stderr, flush=True)
+    return 1
+
+
 def main():
     args = parse()
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    child = os.environ.get("MIJ_BENCH_CHILD") == "1" or os.environ.get("MIJ_BENCH_DIRECT") == "1"
+    if not child and (env_world > 1 or args.gpus > 1):
+        if env_world > 1:        # under an external launcher: its local rank 0 supervises, the others have nothing to do
+            if int(os.environ.get("LOCAL_RANK", "0")) != 0:
+                return 0
+            return supervise(args, env_world, "external launcher (%d ranks): its local rank 0 supervised %d fresh child ranks" % (env_world, env_world))
+        return supervise(args, args.gpus, "self: %d fresh child ranks started and watched by the bench process" % args.gpus)
+    return worker(args)
+
+
+def _progress(rank, what):
+    """Rank 0 of a supervised run tells the supervisor how far it got (its watchdog is on the time between two marks)."""
+    if rank == 0 and os.environ.get("MIJ_BENCH_CHILD") == "1":
+        print("##progress " + what, flush=True)
+
+
+def _inject(rank, gather, where):
+    """Test hook (tests/test_gpu_sharded.py): MIJ_BENCH_INJECT="die|hang:<gather>:<rank>:<where>" makes that rank of a run with
+    that gather exit or stall at that point, so that the supervisor's fallback can be exercised without breaking a GPU."""
+    spec = os.environ.get("MIJ_BENCH_INJECT")
+    if not spec:
+        return
+    kind, g, r, w = (spec.split(":") + ["", "", "", ""])[:4]
+    if g == gather and int(r or 0) == rank and (w or "init") == where:
+        if kind == "die":
+            os._exit(3)
+        time.sleep(10 ** 6)
+
+
+def worker(args):
+    import datetime
     import torch
     import torch.distributed as dist
     import nvjpeg_imagecompressor_amd as mij
@@ -107,20 +282,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    _progress(rank, "imported")
+    if args.gather == "serial":
+        os.environ["MIJ_BENCH_NO_PIPELINE"] = "1"
     # Rehearsal switches (tests only): all ranks on GPU 0 with gloo carrying the collectives, because RCCL refuses two ranks
     # on one device. The measured runs use one GPU per rank over RCCL/xGMI.
     one_device = os.environ.get("MIJ_BENCH_ONE_DEVICE") == "1"
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # A collective that does not complete within the bound ends the rank (RCCL's watchdog), the supervisor sees it die
+        # and starts fresh processes with the next gather: nothing waits for ever.
+        coll_timeout = datetime.timedelta(seconds=float(os.environ.get("MIJ_BENCH_COLL_TIMEOUT_S", "180")))
         if one_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=coll_timeout)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=coll_timeout)
+            ones = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(ones)                    # how many ranks RCCL really joined
+            rccl_ranks = int(ones.item())
+    _progress(rank, "process group up")
+    _inject(rank, args.gather, "init")
     optimize = not args.no_optimize
     W, H = args.width, args.height
 
@@ -163,13 +348,15 @@ def main():
             targets = sharded.open_file_targets(torch, dist, strips if enc is not None else None, rank, world, dev_index, whole_geo)
             if targets is not None:
                 dpipe = sharded.DevicePipeline(torch, dist, strips if enc is not None else None, targets, optimize, device=dev,
-                                               rotate=not args.fixed_root)
+                                               rotate=not args.fixed_root, comms=args.comms)
                 gather_mode = "put"
         if dpipe is None and pipelined:
             unit = sharded.rows_per_restart_unit(whole_geo["mcus_per_row"], whole_geo["restart_interval"])
             if (whole_geo["mcu_rows"] + unit - 1) // unit < world:      # the same arithmetic on every rank: all of them stop
                 raise SystemExit("the send/recv pipeline needs a strip on every rank (more ranks than restart-aligned strips)")
             pipe = sharded.StripPipeline(torch, dist, strips[:2], optimize)
+    _progress(rank, "pipeline ready (%s)" % (gather_mode or "one GPU"))
+    _inject(rank, args.gather, "pipeline")
     timed_handles = [] if dpipe is not None else [e for e in encs if e is not None]
     for e in timed_handles:
         e.enable_timing(True)
@@ -266,7 +453,24 @@ def main():
     for _ in range(args.warmup):
         step(False)
     collect(False)
+    # Put pipeline: one image per ROOT collected and fingerprinted before anything is timed (the timed loop only ever looks at
+    # its last file). Every root must have assembled the same bytes; rank 0 compares them with the timed region's file below.
+    root_files = None
+    if dpipe is not None:
+        mine = []
+        for _ in range(dpipe.nroots):
+            dpipe.step()
+            o = dpipe.collect()
+            if o is not None:
+                b = o.cpu().numpy().tobytes()
+                mine.append("%08x:%d" % (zlib.crc32(b), len(b)))
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        root_files = [c for lst in every for c in lst]
+        if len(set(root_files)) != 1 or len(root_files) != dpipe.nroots:
+            raise SystemExit("put pipeline: the %d roots assembled different files: %s" % (dpipe.nroots, root_files))
     fence()
+    _progress(rank, "warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         jpeg_t = step(True)
@@ -281,11 +485,12 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = (W * H / 1e6) / (ms_per_step / 1e3)
     steps_timed = args.steps
-    if dpipe is not None:
-        # The put pipeline records no per-stage events (nothing in it touches the host). For the stage table, code one more
-        # image the host-synchronised way, outside the timed region, with events on.
-        jpeg_keep = jpeg_t.clone() if jpeg_t is not None else None
-        if dpipe.last_root != 0:      # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
+    _progress(rank, "timed region done")
+    jpeg_keep = jpeg_t.clone() if (world > 1 and jpeg_t is not None) else jpeg_t     # later images reuse the buffers
+    single_ms, put_rate = None, None
+    if world > 1:
+        if dpipe is not None and dpipe.last_root != 0:      # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
+            # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
             lr = dpipe.last_root
             nb = torch.zeros(1, dtype=torch.int64, device=dev)
             if rank == lr:
@@ -296,6 +501,53 @@ def main():
             elif rank == 0:
                 jpeg_keep = torch.empty(int(nb.item()), dtype=torch.uint8, device=dev)
                 dist.recv(jpeg_keep, src=lr)
+        # ONE image alone through the same path, start to complete file (what a caller with a single image waits for; the
+        # `value` above is the rate with several images in flight). Max over ranks, median of five.
+        lat = []
+        for _ in range(5):
+            fence()
+            t1 = time.perf_counter()
+            if dpipe is not None:
+                dpipe.step()
+                dpipe.flush()
+            elif pipe is not None:
+                pipe.step()
+                pipe.flush()
+            else:
+                sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        tl = torch.tensor(lat, dtype=torch.float64, device=dev)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        single_ms = sorted(tl.tolist())[len(lat) // 2] * 1e3
+        if dpipe is not None:
+            # what a link gives k_put: strip bytes / event time around the put, one image alone (no other traffic), a few roots
+            samples = []
+            for e in encs:
+                if e is not None:
+                    e.enable_timing(True)
+            for _ in range(max(1, min(3, dpipe.nroots))):
+                fence()
+                k = dpipe.step()
+                root = dpipe.roots[k]
+                dpipe.flush()
+                if enc is not None and rank != root:
+                    _, p_ms = encs[k].place_times()
+                    samples.append((rank, root, int(dpipe.sizes[k][rank].item()), p_ms))
+            for e in encs:
+                if e is not None:
+                    e.enable_timing(False)
+            every = [None] * world
+            dist.all_gather_object(every, samples)
+            rates = sorted(b / (ms * 1e-3) / 1e9 for lst in every for (_, _, b, ms) in lst if ms > 0 and b > 0)
+            if rates:
+                put_rate = {"min": round(rates[0], 2), "median": round(rates[len(rates) // 2], 2), "max": round(rates[-1], 2), "samples": len(rates),
+                            "strip_MB": round(max(b for lst in every for (_, _, b, _) in lst) / 1e6, 2),
+                            "note": "k_put alone on its stream, hipEvents around it; one image in flight"}
+        _progress(rank, "latency and put rate done")
+    if dpipe is not None:
+        # The put pipeline records no per-stage events (nothing in it touches the host). For the stage table, code one more
+        # image the host-synchronised way, outside the timed region, with events on.
         try:
             if enc is not None:
                 enc.enable_timing(True)
@@ -307,7 +559,7 @@ def main():
             print("stage-time pass failed: %r" % (ex,), file=sys.stderr)
             stage_acc.clear()
         fence()
-        jpeg_t = jpeg_keep
+    jpeg_t = jpeg_keep
 
     # Informational second figure (--also-two-streams; one GPU, headline path only): the same loop with the two images in flight on TWO HIP
     # streams, where one image's narrow kernels (DC statistics, tables, scan) and the wide kernels' tails overlap the other
@@ -336,6 +588,9 @@ def main():
     # ---- rank 0: verify, report ----------------------------------------------------------------------------------
     if rank == 0:
         jpeg = jpeg_t.cpu().numpy().tobytes()
+        fingerprint = "%08x:%d" % (zlib.crc32(jpeg), len(jpeg))
+        if root_files is not None and set(root_files) != {fingerprint}:
+            raise SystemExit("put pipeline: the files collected from the roots (%s) differ from the timed region's file (%s)" % (root_files, fingerprint))
         ratio = len(jpeg) / (3.0 * W * H)
         stages = {k: v / steps_timed for k, v in stage_acc.items()}
         strip_px = rows * W
@@ -352,7 +607,7 @@ def main():
                                  "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
         if stage_roof and not args.progressive:
             dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
-            traffic, traffic_src = measured_traffic(kname[dom], args, optimize and not args.progressive, world)
+            traffic, traffic_src = measured_traffic(kname[dom], args, optimize and not args.progressive, world, mij.library_source_hash())
             roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": stage_roof[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
@@ -373,7 +628,8 @@ def main():
                                    "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
                                                     args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
                        "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
-                       "images_in_flight": n_handles, "gather": gather_mode,
+                       "images_in_flight": n_handles, "gather": gather_mode if os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" or world == 1 else "serial",
+                       "comms": (dpipe.comms if dpipe is not None else None),
                        "root": (None if dpipe is None else ("rank 0" if args.fixed_root else "rotating over the ranks, image by image")),
                        "streams": n_handles if dpipe is not None else (2 if (pipelined and world == 1 and args.two_streams) else 1),
                        "pipeline": ("tables-ahead: image i's table build (one workgroup) on a side stream under image i-1's entropy coder; "
@@ -382,6 +638,20 @@ def main():
             "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None,
             "hbm_copy_ceiling_note": "own 16-B/lane copy kernel (k_copy16), read + write bytes; torch copy_ on the same box: %s GB/s" % (round(copy_lib_gbs, 1) if copy_lib_gbs else None), "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }
+        out["library_source_hash"] = mij.library_source_hash()
+        golden = golden_fingerprint(args, optimize, geo["restart_interval"])
+        if golden is not None:          # the committed fingerprint of this exact configuration (tests/golden/, computed on the CPU)
+            out["golden_match"] = golden == (out["jpeg_crc32"], out["jpeg_bytes"])
+        if world > 1:
+            out["rccl_ranks"] = rccl_ranks
+            out["collective_backend"] = "gloo (one-device rehearsal)" if one_device else "nccl (RCCL)"
+            out["single_image_latency_ms"] = round(single_ms, 4) if single_ms is not None else None
+            out["single_image_latency_note"] = "one image alone, issue to complete file on its root, max over ranks, median of 5"
+            out["put_GB/s"] = put_rate
+            if root_files is not None:
+                out["files_verified"] = {"roots": len(root_files), "identical_to_timed_file": True}
+            if want_put and dpipe is None:
+                out["gather_note"] = "the output buffers could not be peer-mapped (hipIpc*): every rank took send/recv"
         if two_streams:
             out["two_streams"] = two_streams
         if not args.no_psnr:
@@ -407,6 +677,25 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def golden_fingerprint(args, optimize, restart_interval):
+    """(crc32 hex, bytes) of this configuration's file from tests/golden/big_8320x40000_q95.json (written by
+    tests/make_golden_big.py on the CPU), or None when the run is not one of its configurations."""
+    if (args.width, args.height, args.quality) != (W_IMG, H_IMG, QUALITY) or args.progressive or args.fmt not in ("bgr", "rgb"):
+        return None
+    path = os.path.join(ROOT, "tests", "golden", "big_8320x40000_q95.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    css = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5}[args.css]
+    e = d.get("cases", {}).get("css%d_ri%d_%s" % (css, restart_interval, "opt" if optimize else "fix"))
+    if not isinstance(e, dict) or "crc32" not in e:
+        return None
+    return (e["crc32"], e.get("len"))
 
 
 def bpp_stage_b(css):
@@ -443,9 +732,11 @@ def hbm_copy_ceiling(torch, mij, dev):
     return own, lib
 
 
-def measured_traffic(kernel, args, optimize, world):
+def measured_traffic(kernel, args, optimize, world, lib_hash):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/hbm_traffic.py), or None if the passes were
-    taken on a different workload than this run. A process cannot read its own PMC counters; they come from rocprofv3."""
+    taken on a different workload than this run OR on a different build of the library than the one loaded now (the file
+    records the source hash compiled into the library that ran under the counters). A process cannot read its own PMC
+    counters; they come from rocprofv3."""
     import glob
     default = (args.width == W_IMG and args.height == H_IMG and args.css == CSS_NAME and args.quality == QUALITY and optimize and world == 1)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
@@ -453,8 +744,11 @@ def measured_traffic(kernel, args, optimize, world):
         return None, None
     with open(files[-1]) as f:
         d = json.load(f)
+    rel = os.path.relpath(files[-1], ROOT)
+    if d.get("library_source_hash") != lib_hash:
+        return None, "%s was taken on another build of the library (%s...): not quoted" % (rel, str(d.get("library_source_hash"))[:12])
     k = d.get("kernels", {}).get(kernel)
-    return (k["total_bytes"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+    return (k["total_bytes"], rel) if k else (None, None)
 
 
 def _psnr_check(jpeg, W, H, fmt, d_img):
@@ -486,4 +780,4 @@ def _psnr_check(jpeg, W, H, fmt, d_img):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -50,11 +50,11 @@ class NVJPEG_COMPRESS_RUNNER_API NvjpegCompressRunner {
   void setQuality(int quality);
   void setOptimizedHuffman(bool optimize);
   void setRestartInterval(int mcus);       // -1 = automatic
-  void setProgressive(bool progressive);
+  void setProgressive(bool progressive);   // the reference's encoding (ImageCompressorImpl.cu:28); default false = baseline, the fast path
   // Secondary ("difference map") compression, reference README.md:8: first layer into `primary`, the
   // JPEG of the difference map is returned; both environments must be built. secondaryDecode puts the pair back together.
   std::vector<unsigned char> secondaryCompress(cv::Mat image, std::vector<unsigned char> &primary, int *run_state);
-  cv::Mat secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int *run_state);   // the reference's encoding (ImageCompressorImpl.cu:28); default false = baseline, the fast path
+  cv::Mat secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int *run_state);
   void setDevice(int device);
   void setVerbose(bool verbose);
   const char *lastError() const;

@@ -75,7 +75,8 @@ typedef struct mij_encoder_params {
   /* nvjpegEncoderParamsSetEncoding (ImageCompressorImpl.cu:28): 0 = baseline sequential (SOF0, one scan), the default
    * and the fast path; 1 = progressive (SOF2): the same coefficients coded as the ten scans of libjpeg's default script
    * with an optimal Huffman table per scan -- byte-identical to libjpeg-turbo's progressive output, a few per cent
-   * smaller than baseline, about nine times slower to produce (ten gather + emit passes: 15.6 ms at the full size). Whole images only (no strips);
+   * smaller than baseline, about three times slower to produce (a statistics and an emit pass per scan; see DESIGN.md section 4
+   * for the measured times). Whole images only (no strips);
    * optimized_huffman is implied. */
   int progressive;
 } mij_encoder_params;
@@ -161,6 +162,9 @@ MIJ_API int mij_encode_entropy_sizes(mij_encoder *enc, uint64_t *d_size_slot, vo
 MIJ_API int mij_encode_place(mij_encoder *enc, uint8_t *d_file_scan, size_t file_scan_capacity, const uint64_t *d_sizes, int rank,
                              int world, void *stream);
 MIJ_API int mij_sharded_result(mij_encoder *enc, const uint64_t *d_sizes, int rank, int world, mij_result *out);
+/* Device times in ms of the last mij_encode_place (mij_encoder_enable_timing before it): [0] stuffing + compaction,
+ * [1] the put of the strip into the root's peer-mapped buffer (0 on the root). Strip bytes / [1] = what one xGMI link gave. */
+MIJ_API int mij_place_times(mij_encoder *enc, float ms[2]);
 MIJ_API int mij_encoder_reserve_output(mij_encoder *enc, size_t scan_capacity_bytes);
 MIJ_API int mij_output_buffer(mij_encoder *enc, void **d_buffer, size_t *scan_offset, size_t *scan_capacity);
 #define MIJ_IPC_HANDLE_BYTES 64

@@ -50,7 +50,7 @@ def _digest(paths, extra=()):
 
 def source_hash():
     """SHA-256 over all sources, headers and compile flags of libmijpeg.so."""
-    return _digest([os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + _headers(), FLAGS)
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), FLAGS)       # a missing source raises: never a silent partial library
 
 
 def _read(path):
@@ -74,7 +74,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
-            continue
+            raise FileNotFoundError("translation unit %s listed in build.SOURCES is missing" % path)
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         # the tree hash is compiled into mij_api.hip only, so the other objects stay cached across unrelated edits
         defs = ['-DMIJ_SOURCE_HASH="%s"' % want] if src == "mij_api.hip" else []

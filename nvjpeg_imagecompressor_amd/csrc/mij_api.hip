@@ -70,6 +70,8 @@ struct mij_encoder {
   bool host_streams = false;
   hipEvent_t ev[8]{};
   hipEvent_t ev_xdone{}, ev_tab{};   // transform complete / tables built (mij_encode_tables on another stream)
+  hipEvent_t ev_place[3]{};          // mij_encode_place with timing on: before K6, between K6 and k_put, behind k_put
+  bool ev_place_ok = false, place_timed = false, place_put = false;
   bool tables_early = false;         // this image's tables were built by mij_encode_tables
   hipEvent_t ev_done{};      // recorded behind the result copy: mij_encode_result waits for THIS encode only, so that a caller
                              // who alternates two handles on one stream keeps the GPU busy while it collects a result
@@ -184,6 +186,7 @@ void mij_encoder_destroy(mij_encoder *e) {
   (void)hipFree(e->d_out); (void)hipFree(e->d_res); (void)hipFree(e->d_src); (void)hipFree(e->d_sec);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->ev_place_ok) for (auto &v : e->ev_place) (void)hipEventDestroy(v);
   if (e->ev_ok) { for (auto &v : e->ev) (void)hipEventDestroy(v); (void)hipEventDestroy(e->ev_done); (void)hipEventDestroy(e->ev_xdone); (void)hipEventDestroy(e->ev_tab); }
   (void)hipFree(e->d_prog);
   if (e->h_prog_tab) (void)hipHostFree(e->h_prog_tab);
@@ -749,10 +752,19 @@ int mij_encode_place(mij_encoder *e, uint8_t *d_file_scan, size_t file_scan_capa
   // straight to its place in the file; every other rank compacts locally and puts the strip into the root's buffer.
   const bool is_root = !d_file_scan || d_file_scan == own_scan;
   const unsigned long long *szs = reinterpret_cast<const unsigned long long *>(d_sizes);
+  e->place_timed = e->timing;
+  if (e->place_timed && !e->ev_place_ok) {
+    for (auto &v : e->ev_place) HIPCHK(e, hipEventCreate(&v));
+    e->ev_place_ok = true;
+  }
+  if (e->place_timed) HIPCHK(e, hipEventRecord(e->ev_place[0], s));
   HIPCHK(e, launch_compact(e->g, e->d_scratch, e->slot_bytes, e->d_seg_bytes, e->d_seg_off, e->d_chunk_base, e->nseg, own_scan, e->capacity,
                            e->d_res, s, e->fuse ? e->d_redo : nullptr, nullptr, is_root ? szs : nullptr, rank, world));      // fused: only if the fused placement was given up
+  if (e->place_timed) HIPCHK(e, hipEventRecord(e->ev_place[1], s));
   if (!is_root)
     HIPCHK(e, launch_put(own_scan, szs, rank, world, d_file_scan, file_scan_capacity, e->capacity, e->d_res, s));
+  if (e->place_timed) HIPCHK(e, hipEventRecord(e->ev_place[2], s));
+  e->place_put = !is_root;
   e->placed_as_root = is_root;
   HIPCHK(e, hipEventRecord(e->ev_done, s));
   e->last_stream = s;
@@ -785,6 +797,22 @@ int mij_sharded_result(mij_encoder *e, const uint64_t *d_sizes, int rank, int wo
   o->scan_offset = HDR_AREA;
   o->scan_bytes = e->placed_as_root ? (size_t)total : (size_t)sz[(size_t)rank];
   o->file_bytes = hb + o->scan_bytes;
+  return MIJ_OK;
+}
+
+// Device times of the last mij_encode_place on this handle (timing enabled before it, mij_sharded_result called since):
+// [0] stuffing + compaction (K6), [1] the put into the root's buffer (0 on the root itself, which has nothing to send).
+int mij_place_times(mij_encoder *e, float ms[2]) {
+  if (!e || !ms) return MIJ_ERR_INVALID_ARG;
+  if (!e->place_timed || !e->ev_place_ok) return fail(e, MIJ_ERR_NOT_READY, "timing was not enabled for the last mij_encode_place");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  HIPCHK(e, hipEventSynchronize(e->ev_place[2]));
+  for (int i = 0; i < 2; i++) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, e->ev_place[i], e->ev_place[i + 1]) != hipSuccess) t = -1.f;
+    ms[i] = t;
+  }
+  if (!e->place_put) ms[1] = 0.f;
   return MIJ_OK;
 }
 

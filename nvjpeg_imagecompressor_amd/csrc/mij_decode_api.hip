@@ -352,6 +352,10 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   // entropy-coded bytes of all scans, from the first scan's data to the end of the last one's
   const size_t data_off = ps.scans.front().off;
   const size_t scan_len = ps.fast ? jpeg_bytes - data_off : ps.scans.back().off + ps.scans.back().len - data_off;
+  // The subsequence-parallel and the wave decoders keep positions inside a scan as 32-bit byte offsets (k_decode_par.inc
+  // ParReader, k_decode_wave.inc): a file with 4 GiB or more of entropy-coded data (65535 x 65535 noise at q100 can get
+  // there) is refused instead of being decoded from truncated offsets.
+  if (scan_len >= ((size_t)1 << 32) - 64) return dfail(d, MIJ_ERR_BAD_STREAM, "entropy-coded data of 4 GiB or more is not supported");
   long long max_seg = 1;
   size_t max_len = 0;
   for (const auto &sc : ps.scans) {

@@ -87,6 +87,12 @@ class Encoder:
         _lib.check(self._L.mij_sharded_result(self._h, C.c_void_p(d_sizes), rank, world, C.byref(r)), self._h, "mij_sharded_result")
         return {f[0]: getattr(r, f[0]) for f in r._fields_}
 
+    def place_times(self):
+        """(ms of stuffing + compaction, ms of the put into the root's buffer) of the last `place` issued with timing on."""
+        ms = (C.c_float * 2)()
+        _lib.check(self._L.mij_place_times(self._h, ms), self._h, "mij_place_times")
+        return float(ms[0]), float(ms[1])
+
     def reserve_output(self, scan_capacity):
         _lib.check(self._L.mij_encoder_reserve_output(self._h, scan_capacity), self._h, "mij_encoder_reserve_output")
 
@@ -287,6 +293,12 @@ def pinned_empty(shape, dtype=np.uint8):
     buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
     buf._mij_owner = _PinnedBlock(L, ptr)    # freed when the last array over `buf` is gone
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def library_source_hash():
+    """SHA-256 (hex) of the sources the LOADED libmijpeg.so was compiled from (mij_source_hash): what build.source_hash()
+    gives for the tree it belongs to."""
+    return _lib.load().mij_source_hash().decode()
 
 
 def copy_bench_device(d_dst, d_src, nbytes, stream=0):

@@ -18,7 +18,8 @@ Everything else is local arithmetic. Two orchestrations of those steps:
   (N - 1) / N of a file over its inbound links (one per peer, ~77 GB/s each way), which at 8 GPUs is 0.33 ms per 204-MB file --
   more than the 0.16 ms a rank computes on its eighth of the image -- so with a fixed root the links into rank 0 would set the
   pace; rotating spreads the inbound traffic over every GPU's links. DEPTH images are in flight per rank, each on its own
-  stream and its own communicator, so that one image's collectives and its put run under the other images' kernels.
+  stream, so that one image's collectives and its put run under the other images' kernels; all collectives go through ONE
+  communicator in one global order (an image's all-gather is issued behind the next image's all-reduce, see the class).
   Nothing in a steady-state step waits on the host.
 * `StripPipeline` / `encode_step` (fallback when the peer mapping is unavailable, and the simple one-image form): sizes
   come to the host, strips travel as RCCL send/recv.
@@ -66,6 +67,7 @@ class HipStripEncoder:
     def __init__(self, torch, enc, d_img, fmt="bgr", shared_statistics=True):
         self.torch, self.enc, self.d_img, self.fmt = torch, enc, d_img, fmt
         self.pitch = d_img.stride(0) * d_img.element_size()
+        self.shared_statistics = shared_statistics
         self.d_hist = torch.zeros(4 * 257, dtype=torch.int32, device=d_img.device)
         # The statistics go to a tensor a collective can reduce in place. A single rank has nothing to reduce and leaves the
         # handle on its own buffers (shared_statistics=False): those alternate and need no clearing per image.
@@ -141,6 +143,16 @@ class HipStripEncoder:
         return t
 
 
+def _check_statistics(strips, world, optimize):
+    """A strip encoder created with shared_statistics=False keeps its statistics in the handle's own buffers: what its
+    transform() returns is NOT what the handle counts into, so reducing it over ranks would leave every rank on its local
+    statistics -- different DHTs inside one file. Only a single rank (nothing to reduce) may run that way."""
+    if world > 1 and optimize:
+        for s in (strips or []):
+            if s is not None and getattr(s, "shared_statistics", True) is False:
+                raise ValueError("a strip encoder with shared_statistics=False cannot take part in a multi-rank encode with optimised tables")
+
+
 def device_bytes(torch, ptr, nbytes, device):
     """uint8 tensor view over device memory owned by libmijpeg (valid until the next encode on that handle)."""
     class _Holder:
@@ -156,21 +168,32 @@ def device_bytes(torch, ptr, nbytes, device):
 class DevicePipeline:
     """DEPTH images in flight per rank; per image and rank, enqueued without a single host wait:
 
-        slot k = i % DEPTH, on stream S_k and communicator G_k:
+        slot k = i % DEPTH, on stream S_k:
           transform(i) -> all_reduce(statistics) -> entropy_sizes(i) -> all_gather(sizes) -> place(i)
 
     Image i is assembled on its ROOT, rank i % (number of ranks that own a strip) -- rank 0 always with rotate=False. `place`
     on the root compacts the strip straight to its place in the root's own buffer of slot k; on every other rank it compacts
-    locally and puts the strip into that buffer at the offset a kernel derives from the gathered sizes. One communicator per
-    slot: collectives of different images then do not queue behind each other (on one communicator the next image's
-    all-reduce would wait for this image's all-gather, which waits for this image's entropy coder). Every rank issues the
+    locally and puts the strip into that buffer at the offset a kernel derives from the gathered sizes. Every rank issues the
     same collectives in the same order.
+
+    Communicators (`comms`):
+      * "ordered" (default): ONE communicator for every slot, so the collectives of all images execute in one global order
+        on every rank -- the order they are issued in, which is the same everywhere. So that an image's all-reduce does not
+        queue behind the previous image's all-gather (which waits for that image's entropy coder), the all-gather and
+        placement of image i are issued one step late, BEHIND the all-reduce of image i + 1:
+            AR(0) | AR(1) AG(0) | AR(2) AG(1) | ...
+        Each image's entropy chain then starts as soon as its own statistics are reduced; two images' chains overlap.
+      * "per-slot": one communicator per slot, collectives of different images independent of each other. Several
+        communicators in flight on several streams is a pattern PyTorch documents as unsafe without external ordering
+        (ranks may run the collectives of different communicators in different orders); it is kept as an experiment switch
+        (`bench.py --comms per-slot`) until a multi-GPU node has run it.
 
     Hazards, all resolved by stream order: a handle (coefficients, scratch, output buffer) is reused by image i + DEPTH on
     the same stream; a peer's put of image i + DEPTH into a root's buffer k can only start after the all-gather of that
     image, i.e. after that root has executed everything of image i on its S_k -- including, when it was not image i's root,
     its own put out of that buffer. The file of image i is complete on its root once a LATER collective of slot k has
-    completed there (each peer enqueues it behind its put) -- `collect` issues one.
+    completed there (each peer enqueues it behind its put) -- `collect` issues one, and then agrees on a status word over all
+    ranks, so that a strip some rank failed to place fails the image EVERYWHERE (the root cannot see a peer's flags).
 
     `strips` holds DEPTH strip encoders, or None on a rank that owns no strip (more ranks than restart-aligned strips):
     such a rank contributes zero statistics and a zero size and is never a root (empty ranks come last, partition_mcu_rows).
@@ -178,10 +201,13 @@ class DevicePipeline:
     (`open_file_targets` for the HIP encoder).
     """
 
-    def __init__(self, torch, dist, strips, targets, optimize, device=None, use_streams=None, rotate=True):
+    def __init__(self, torch, dist, strips, targets, optimize, device=None, use_streams=None, rotate=True, comms="ordered"):
+        assert comms in ("ordered", "per-slot")
         self.torch, self.dist, self.strips, self.targets, self.optimize = torch, dist, strips, targets, optimize
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        _check_statistics(strips, self.world, optimize)
         self.depth = len(targets)
+        self.comms = comms
         has = [None] * self.world
         dist.all_gather_object(has, strips is not None)
         self.nroots = sum(1 for h in has if h) if rotate else 1     # ranks 0 .. nroots-1 own strips
@@ -196,12 +222,17 @@ class DevicePipeline:
         if self.use_streams:
             for s in self.streams:
                 s.wait_stream(torch.cuda.current_stream(device))      # the image was produced on the current stream
-        self.groups = [dist.new_group() for _ in range(self.depth)]   # same order on every rank
+        if comms == "per-slot":
+            self.groups = [dist.new_group() for _ in range(self.depth)]   # same order on every rank
+        else:
+            self.groups = [None] * self.depth                             # the default group: one order for everything
         self.mine = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.depth)]
         self.sizes = [torch.zeros(self.world, dtype=torch.int64, device=device) for _ in range(self.depth)]
         self.zero_hist = [torch.zeros(4 * 257, dtype=torch.int32, device=device) for _ in range(self.depth)]
         self.done = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(self.depth)]
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.i = 0
+        self.deferred = None      # "ordered": slot whose all-gather + placement are still to be issued
         self.pending = []         # slots whose image has been issued and not yet collected, oldest first
 
     def _ctx(self, k):
@@ -209,18 +240,37 @@ class DevicePipeline:
         return self.torch.cuda.stream(self.streams[k]) if self.use_streams else contextlib.nullcontext()
 
     def _all_gather(self, out, inp, group):
-        try:
-            self.dist.all_gather_into_tensor(out, inp, group=group)
-        except (RuntimeError, AttributeError):       # a backend without the flat form
-            parts = [self.torch.empty_like(inp) for _ in range(self.world)]
-            self.dist.all_gather(parts, inp, group=group)
-            out.copy_(self.torch.cat(parts))
+        if hasattr(self.dist, "all_gather_into_tensor"):
+            try:
+                self.dist.all_gather_into_tensor(out, inp, group=group)
+                return
+            except NotImplementedError:      # a backend without the flat form; real failures of the collective propagate
+                pass
+        parts = [self.torch.empty_like(inp) for _ in range(self.world)]
+        self.dist.all_gather(parts, inp, group=group)
+        out.copy_(self.torch.cat(parts))
+
+    def _gather_place(self, k):
+        """Second half of slot k's image: sizes all-gathered device to device, strip placed / put."""
+        st = self.strips[k] if self.strips else None
+        sh = self.streams[k].cuda_stream if self.use_streams else 0
+        with self._ctx(k):
+            self._all_gather(self.sizes[k], self.mine[k], self.groups[k])
+            if st is not None:
+                st.place(self.targets[k][self.roots[k]], self.sizes[k], self.rank, self.world, sh)
+
+    def _issue_deferred(self):
+        if self.deferred is not None:
+            k, self.deferred = self.deferred, None
+            self._gather_place(k)
 
     def step(self):
-        """Issue the next image on slot i % DEPTH and return at once (no host wait, no collective beyond the image's own
-        two). An older image still uncollected in that slot is overwritten: its file stays valid only until the peers' puts of
-        the new image start, so callers that want EVERY file call `collect` before the slot comes round again."""
+        """Issue the next image on slot i % DEPTH and return at once (no host wait, no collective beyond the images' own
+        two per step). An older image still uncollected in that slot is overwritten: its file stays valid only until the
+        peers' puts of the new image start, so callers that want EVERY file call `collect` before the slot comes round again."""
         k = self.i % self.depth
+        if self.deferred == k:           # depth 1: the slot's previous image must be placed before its buffers are reused
+            self._issue_deferred()
         root = self.roots[k] = self.last_root = self.i % self.nroots
         self.pending = [q for q in self.pending if q != k]
         self.i += 1
@@ -232,33 +282,50 @@ class DevicePipeline:
                 self.dist.all_reduce(hist, group=self.groups[k])
             if st is not None:
                 st.entropy_sizes(self.mine[k], sh)
-            self._all_gather(self.sizes[k], self.mine[k], self.groups[k])
-            if st is not None:
-                st.place(self.targets[k][root], self.sizes[k], self.rank, self.world, sh)
+            else:
+                self.mine[k].zero_()
+        if self.comms == "ordered":
+            self._issue_deferred()       # the previous image's all-gather, BEHIND this image's all-reduce
+            self.deferred = k
+        else:
+            self._gather_place(k)
         self.pending.append(k)
         return k
 
     def collect(self, want_file=True):
         """Complete the OLDEST pending image: one small collective behind every rank's put, a wait for this rank's stream,
-        then (on the image's root, if wanted) the assembled file; None on every other rank. Every rank must call this the same
-        number of times, in the same order relative to `step`. Not part of a steady-state step: the bench only flushes at the
-        end of the timed region."""
+        a status word agreed over all ranks, then (on the image's root, if wanted) the assembled file; None on every other
+        rank. Every rank must call this the same number of times, in the same order relative to `step`. Not part of a
+        steady-state step: the bench only flushes at the end of the timed region."""
         if not self.pending:
             return None
         k = self.pending.pop(0)
+        if self.deferred == k:
+            self._issue_deferred()
         with self._ctx(k):
             self.dist.all_reduce(self.done[k], group=self.groups[k])
         if self.use_streams:
             self.streams[k].synchronize()
         st = self.strips[k] if self.strips else None
-        if st is None:
-            return None
-        out = st.file(self.targets[k][self.roots[k]], self.sizes[k], self.rank, self.world)   # also checks this handle's status
+        out, err = None, None
+        if st is not None:
+            try:
+                out = st.file(self.targets[k][self.roots[k]], self.sizes[k], self.rank, self.world)   # also checks this handle's status
+            except Exception as e:       # noqa: BLE001 -- reported on every rank below
+                err = e
+        # A peer whose put refused to write (or whose handle failed) knows it; the root does not. Agree before anyone
+        # hands out a file with a hole in it.
+        self.status.fill_(0 if err is None else 1)
+        self.dist.all_reduce(self.status, op=self.dist.ReduceOp.MAX, group=self.groups[k])
+        if int(self.status.item()):
+            raise RuntimeError("sharded encode failed on %s: %s" % ("this rank" if err is not None else "another rank",
+                                                                    err if err is not None else "see that rank's log"))
         return out if (want_file and self.rank == self.roots[k]) else None
 
     def flush(self):
         """Complete everything in flight; returns (on rank `last_root`) the file of the LAST image issued."""
         out = None
+        self._issue_deferred()
         while self.pending:
             out = self.collect(want_file=len(self.pending) == 1)
         if self.use_streams:
@@ -327,6 +394,7 @@ def encode_step(torch, dist, strip_encoder, optimize, out_cache, stream=0):
     uint8 tensor holding the complete JFIF file (a view into `out_cache["buf"]`, reused across calls); None on the other
     ranks. `strip_encoder` may be None on a rank that owns no strip."""
     world = dist.get_world_size() if dist.is_initialized() else 1
+    _check_statistics([strip_encoder], world, optimize)
     hist = strip_encoder.transform(stream) if strip_encoder is not None else torch.zeros(4 * 257, dtype=torch.int32, device=out_cache.get("device", "cpu"))
     if world > 1 and optimize:
         dist.all_reduce(hist)                      # the only collective on the data path before entropy coding
@@ -360,6 +428,7 @@ class StripPipeline:
 
     def __init__(self, torch, dist, strips, optimize):
         assert len(strips) == 2
+        _check_statistics(strips, dist.get_world_size() if dist.is_initialized() else 1, optimize)
         self.torch, self.dist, self.strips, self.optimize = torch, dist, strips, optimize
         self.caches = [{}, {}]
         self.i, self.pending = 0, None

@@ -8,8 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+SHIPPED = {}      # state of the in-tree libmijpeg.so as it ARRIVED, before any fixture could rebuild it
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        from nvjpeg_imagecompressor_amd import build as B
+        SHIPPED.update(present=os.path.exists(B.LIB), stale=B.needs_build(), tree_hash=B.source_hash())
+    except Exception as e:       # noqa: BLE001 -- reported by the test that reads this
+        SHIPPED.update(error=repr(e))
 
 
 @pytest.fixture(scope="session")

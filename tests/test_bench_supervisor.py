@@ -1,0 +1,133 @@
+"""The supervisor of `python bench.py --gpus N` (bench.py: supervise / _run_attempt) without a GPU: child ranks are played by
+tiny scripts that speak the children's protocol on stdout ("##progress ..." marks, one JSON line). What is under test is the
+launcher's behaviour on first contact with a node: relay of rank 0's line, exit status, the fallback ladder
+put -> sendrecv -> serial with FRESH processes after a rank died or the run stalled, and that only its own children are killed."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHILD = r'''
+import json, os, sys, time
+rank, world, mode = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
+plan = json.loads(os.environ["FAKE_PLAN"]).get(mode, "ok")
+open(os.environ["FAKE_LOG"], "a").write("%s %d %d\n" % (mode, rank, os.getpid()))
+assert os.environ["MIJ_BENCH_CHILD"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+if rank == 0:
+    print("##progress imported", flush=True)
+if plan == "die":
+    if rank == 1:
+        os._exit(3)
+    time.sleep(600)          # the others wait for a collective that never completes
+if plan == "hang":
+    if rank == 0:
+        print("##progress process group up", flush=True)
+    time.sleep(600)
+if plan == "hang_teardown":
+    if rank == 0:
+        print(json.dumps({"value": 1.0, "config": {"gather": mode}}), flush=True)
+    time.sleep(600)
+if rank == 0:
+    print("stray line", flush=True)
+    print(json.dumps({"value": 1.0, "n_gpus": world, "config": {"gather": mode}}), flush=True)
+'''
+
+
+@pytest.fixture
+def bench(monkeypatch, tmp_path):
+    import importlib
+    b = importlib.import_module("bench")
+    script = tmp_path / "child.py"
+    script.write_text(CHILD)
+    monkeypatch.setattr(b, "_child_argv", lambda mode: [sys.executable, str(script), mode])
+    monkeypatch.setenv("FAKE_LOG", str(tmp_path / "log.txt"))
+    monkeypatch.setenv("MIJ_BENCH_WATCHDOG_S", "3")
+    monkeypatch.setenv("MIJ_BENCH_WATCHDOG_INIT_S", "30")
+    b._log = str(tmp_path / "log.txt")
+    return b
+
+
+class Args:
+    gather, no_fallback, progressive = "put", False, False
+
+
+def _run(bench, capsys, plan, monkeypatch, world=3, **kw):
+    monkeypatch.setenv("FAKE_PLAN", json.dumps(plan))
+    a = Args()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    rc = bench.supervise(a, world, "test")
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    log = [l.split() for l in open(bench._log).read().splitlines()]
+    return rc, (json.loads(out[-1]) if out else None), log
+
+
+def _gone(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return True
+    # a zombie of ours still answers kill(0): reap-state check
+    try:
+        return open("/proc/%d/stat" % pid).read().split()[2] == "Z"
+    except OSError:
+        return True
+
+
+def test_clean_run_relays_rank0_line(bench, capsys, monkeypatch):
+    rc, d, log = _run(bench, capsys, {}, monkeypatch)
+    assert rc == 0 and d["config"]["gather"] == "put" and d["gather_fallback"] is None and d["launcher"] == "test"
+    assert sorted(int(r) for m, r, _ in log) == [0, 1, 2] and {m for m, _, _ in log} == {"put"}
+
+
+def test_dead_rank_falls_back_with_fresh_processes(bench, capsys, monkeypatch):
+    rc, d, log = _run(bench, capsys, {"put": "die"}, monkeypatch)
+    assert rc == 0 and d["config"]["gather"] == "sendrecv"
+    assert "put: rank 1 exited with status 3" in d["gather_fallback"]
+    pids = {}
+    for m, r, pid in log:
+        pids.setdefault(m, set()).add(int(pid))
+    assert len(pids["put"]) == 3 and len(pids["sendrecv"]) == 3 and not (pids["put"] & pids["sendrecv"])     # fresh processes
+    assert all(_gone(p) for p in pids["put"])
+
+
+def test_stalled_run_is_killed_and_the_ladder_descends_to_serial(bench, capsys, monkeypatch):
+    t0 = time.monotonic()
+    rc, d, log = _run(bench, capsys, {"put": "hang", "sendrecv": "die"}, monkeypatch)
+    assert rc == 0 and d["config"]["gather"] == "serial"
+    assert "put: no progress for 3 s after 'process group up'" in d["gather_fallback"] and "sendrecv: rank 1 exited" in d["gather_fallback"]
+    assert time.monotonic() - t0 < 60
+    assert all(_gone(int(pid)) for m, _, pid in log if m == "put")         # the hung ranks were ended, exactly those
+
+
+def test_every_gather_failing_is_an_error_not_a_line(bench, capsys, monkeypatch):
+    rc, d, _ = _run(bench, capsys, {"put": "die", "sendrecv": "die", "serial": "die"}, monkeypatch)
+    assert rc == 1 and d is None
+    rc, d, _ = _run(bench, capsys, {"put": "die"}, monkeypatch, no_fallback=True)
+    assert rc == 1 and d is None
+
+
+def test_result_stands_when_a_rank_hangs_in_teardown(bench, capsys, monkeypatch):
+    rc, d, log = _run(bench, capsys, {"put": "hang_teardown"}, monkeypatch, world=2)
+    assert rc == 0 and d["config"]["gather"] == "put" and "ended by the supervisor" in d["teardown_note"]
+    assert all(_gone(int(pid)) for _, _, pid in log)
+
+
+def test_plain_command_line_needs_no_launcher():
+    """`python bench.py --gpus 2` on a box without a GPU: the supervisor itself runs (no 'needs torch.distributed.run' exit),
+    starts ranks, sees them fail for lack of a device and reports that -- without ever importing torch itself."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the N > 1 path is exercised by tests/test_gpu_sharded.py")
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-fallback"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 1 and "gather 'put' failed" in r.stderr
+    # -X importtime is a flag of the PARENT interpreter only (the children are started without it): its import log is the parent's
+    imported = [l.split("|")[-1].strip() for l in r.stderr.splitlines() if l.startswith("import time:")]
+    assert imported and "torch" not in imported and "nvjpeg_imagecompressor_amd" not in imported

@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 CSS_ALL = [0, 1, 2, 3, 4, 5]
 
 
+def test_the_library_on_this_box_is_the_tree(mij):
+    """On the GPU box: the libmijpeg.so that travelled with the snapshot was built from exactly these sources (checked when
+    pytest started, before any fixture could rebuild it), and the library this process has loaded says so itself."""
+    from conftest import SHIPPED
+    from nvjpeg_imagecompressor_amd import build as B
+    assert "error" not in SHIPPED, SHIPPED
+    assert SHIPPED["present"] and not SHIPPED["stale"], "the shipped libmijpeg.so did not match the sources: %s" % SHIPPED
+    assert mij.library_source_hash() == B.source_hash() == SHIPPED["tree_hash"]
+
+
 def _img(oracle, W, H, kind, seed=0):
     if kind == "synth":
         return oracle.synth_rgb(W, H)

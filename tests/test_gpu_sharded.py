@@ -52,7 +52,7 @@ def _noise_image(W, rows):
     return full
 
 
-def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path, noise=False, backend="gloo"):
+def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_each, out_path, noise=False, backend="gloo", comms="ordered"):
     """sharded.DevicePipeline on real HIP handles: DEPTH images in flight, peer-mapped rank-0 buffers, k_put."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":       # RCCL, initialised the way bench.py does it (one rank: RCCL refuses two ranks on one device)
@@ -84,7 +84,7 @@ def _device_worker(rank, world, port, W, H, css, optimize, ri, nimg, collect_eac
         assert r0 == r1 and rank > 0
     targets = sharded.open_file_targets(torch, dist, strips, rank, world, 0, whole)
     assert targets is not None, "hipIpc mapping of rank 0's buffers failed"
-    pipe = sharded.DevicePipeline(torch, dist, strips, targets, optimize, device=dev)
+    pipe = sharded.DevicePipeline(torch, dist, strips, targets, optimize, device=dev, comms=comms)
     outs = []
     for i in range(nimg):
         if strips is not None:
@@ -130,21 +130,23 @@ def test_device_pipeline_put_gather(oracle, tmp_path, world, css, optimize, ri, 
         assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want), i
 
 
-def test_device_pipeline_over_rccl_single_rank(oracle, tmp_path):
+@pytest.mark.parametrize("comms", ["ordered", "per-slot"])
+def test_device_pipeline_over_rccl_single_rank(oracle, tmp_path, comms):
     """The one thing a one-GPU box can show about the measured configuration: the pipeline's calls as RCCL takes them -- the
-    eager communicator, four split communicators, the int32 statistics all-reduce on a handle's own memory, the int64 sizes
-    all-gather, stream order between the library's kernels and RCCL's -- with a single rank (its own root), five images,
-    four in flight, files against the oracle."""
+    eager communicator (every collective of every slot on it, in issue order: the default) or four split communicators, the
+    int32 statistics all-reduce on a handle's own memory, the int64 sizes all-gather, the status all-reduce of `collect`, stream
+    order between the library's kernels and RCCL's -- with a single rank (its own root), six images, four in flight, files
+    against the oracle."""
     import numpy as np
     W, H, nimg = 2080, 1000, 6
     out = str(tmp_path / "rccl.jpg")
-    mp.spawn(_device_worker, args=(1, _free_port(), W, H, 1, True, -1, nimg, False, out, False, "nccl"), nprocs=1, join=True)
+    mp.spawn(_device_worker, args=(1, _free_port(), W, H, 1, True, -1, nimg, False, out, False, "nccl", comms), nprocs=1, join=True)
     dri = int(open(out + ".ri").read())
     full = oracle.synth_rgb(W, H + 8 * nimg)
     want = oracle.encode(np.ascontiguousarray(full[8 * (nimg - 1):8 * (nimg - 1) + H]), 95, 1, True, dri)
     assert open(out + ".%d" % (nimg - 1), "rb").read() == want
     out2 = str(tmp_path / "rccl_each.jpg")
-    mp.spawn(_device_worker, args=(1, _free_port(), W, H, 2, True, -1, 3, True, out2, False, "nccl"), nprocs=1, join=True)
+    mp.spawn(_device_worker, args=(1, _free_port(), W, H, 2, True, -1, 3, True, out2, False, "nccl", comms), nprocs=1, join=True)
     for i in range(3):
         want = oracle.encode(np.ascontiguousarray(full[8 * i:8 * i + H]), 95, 2, True, int(open(out2 + ".ri").read()))
         assert open(out2 + ".%d" % i, "rb").read() == want, i
@@ -182,29 +184,65 @@ def test_hip_strips_five_ranks_uneven(oracle, tmp_path):
     assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want)
 
 
-@pytest.mark.parametrize("pipeline", ["put", "sendrecv", None])
-def test_bench_multi_rank_rehearsal(tmp_path, pipeline):
-    """bench.py's N > 1 path end to end (launcher, strips, collectives, gather, the JSON line), rehearsed with three ranks
-    on the one GPU over gloo: the file must be the single-GPU file. All three forms of the step: four images in flight
-    with the put gather and a rotating root (sharded.DevicePipeline, the default), two in flight with send/recv (sharded.StripPipeline, the
-    fallback) and one at a time (sharded.encode_step)."""
+def _bench(args, env_extra=None, launcher=False, timeout=900):
     import json
     import subprocess
-    env = dict(os.environ, MIJ_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    if pipeline is None:
-        env["MIJ_BENCH_NO_PIPELINE"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1",
-           "--no-cpu-baseline", "--height", "4000"] + (["--gather", pipeline] if pipeline else [])
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    env = dict(os.environ, MIJ_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MIJ_BENCH_CHILD", "MIJ_BENCH_DIRECT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = [sys.executable]
+    if launcher:
+        port = str(_free_port())
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher), "--master-addr", "127.0.0.1", "--master-port", port]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stderr
+
+
+@pytest.fixture(scope="module")
+def one_gpu_line():
+    d, _ = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-psnr", "--height", "4000"])
+    assert d["n_gpus"] == 1 and "launcher" not in d          # N = 1 runs in the process of the command line, as ever
+    return d
+
+
+@pytest.mark.parametrize("gather,comms", [("put", "ordered"), ("put", "per-slot"), ("sendrecv", None), ("serial", None)])
+def test_bench_multi_rank_rehearsal(one_gpu_line, gather, comms):
+    """PLAIN `python bench.py --gpus 3` -- no launcher in the command -- end to end (self-launched fresh ranks, strips,
+    collectives, gather, the JSON line), rehearsed with three ranks on the one GPU over gloo: the file must be the single-GPU
+    file. All forms of the step: four images in flight with the put gather and a rotating root (sharded.DevicePipeline, on
+    one ordered communicator -- the default -- and on one communicator per slot), two in flight with send/recv
+    (sharded.StripPipeline) and one at a time (sharded.encode_step)."""
+    d, _ = _bench(["--gpus", "3", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--height", "4000", "--gather", gather]
+                  + (["--comms", comms] if comms else []))
     assert d["n_gpus"] == 3 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == {"put": 4, "sendrecv": 2, None: 1}[pipeline]
-    assert d["config"]["gather"] == (pipeline or "sendrecv")
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-psnr", "--height", "4000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert one.returncode == 0, one.stderr[-3000:]
-    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["jpeg_crc32"] == d1["jpeg_crc32"] and d["jpeg_bytes"] == d1["jpeg_bytes"] and abs(d["psnr_db"] - 31.1) < 0.3
+    assert d["config"]["parallelism"] == "strips3" and d["config"]["images_in_flight"] == {"put": 4, "sendrecv": 2, "serial": 1}[gather]
+    assert d["config"]["gather"] == gather and d["gather_fallback"] is None and d["launcher"].startswith("self: 3 fresh child ranks")
+    assert d["config"]["comms"] == comms
+    assert d["jpeg_crc32"] == one_gpu_line["jpeg_crc32"] and d["jpeg_bytes"] == one_gpu_line["jpeg_bytes"] and abs(d["psnr_db"] - 31.1) < 0.3
+    assert d["library_source_hash"] == one_gpu_line["library_source_hash"]
+    assert d["single_image_latency_ms"] > 0 and d["rccl_ranks"] is None and "gloo" in d["collective_backend"]
+    if gather == "put":
+        assert d["files_verified"] == {"roots": 3, "identical_to_timed_file": True}
+        assert d["put_GB/s"]["samples"] >= 2 and d["put_GB/s"]["min"] > 0
+
+
+def test_bench_under_an_external_launcher(one_gpu_line):
+    """The driver's documented command shape: torch.distributed.run starts N ranks of bench.py. Its local rank 0 supervises N
+    fresh children (the same ones the plain command starts), the launcher's other ranks leave at once."""
+    d, _ = _bench(["--gpus", "3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-psnr", "--height", "4000"], launcher=3)
+    assert d["n_gpus"] == 3 and d["config"]["gather"] == "put" and d["launcher"].startswith("external launcher (3 ranks)")
+    assert d["jpeg_crc32"] == one_gpu_line["jpeg_crc32"]
+
+
+@pytest.mark.parametrize("inject,expect", [("die:put:1:pipeline", "put: rank 1 exited with status 3"),
+                                           ("hang:put:2:pipeline", "put: no progress for")])
+def test_bench_falls_back_to_send_recv_with_fresh_ranks(one_gpu_line, inject, expect):
+    """A rank of the put pipeline dies / stalls: the supervisor ends the ranks it started and starts fresh ones with send/recv;
+    the line says why, and the file is still the single-GPU file."""
+    d, err = _bench(["--gpus", "3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-psnr", "--height", "4000"],
+                    env_extra={"MIJ_BENCH_INJECT": inject, "MIJ_BENCH_WATCHDOG_S": "45"})
+    assert d["config"]["gather"] == "sendrecv" and expect in d["gather_fallback"], d["gather_fallback"]
+    assert d["jpeg_crc32"] == one_gpu_line["jpeg_crc32"] and "starting fresh ranks" in err

@@ -125,7 +125,7 @@ def _worker(rank, world, port, W, H, css, optimize, ri, q, out_path):
     dist.destroy_process_group()
 
 
-def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, collect_each, targets, out_path, rotate):
+def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg, collect_each, targets, out_path, rotate, comms="ordered"):
     """DevicePipeline: `nimg` different images; either every file is collected before its slot comes round again
     (collect_each) or the loop runs like the bench -- issue only, one flush at the end, which yields the LAST file."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -144,7 +144,7 @@ def _device_pipeline_worker(rank, world, port, W, H, css, optimize, ri, q, nimg,
         for k, e in enumerate(encs):
             e.own = targets[k][rank]
     mine = [[None if r == rank else t for r, t in enumerate(row)] for row in targets]      # what open_file_targets returns
-    pipe = sharded.DevicePipeline(torch, dist, encs, mine, optimize, device=torch.device("cpu"), rotate=rotate)
+    pipe = sharded.DevicePipeline(torch, dist, encs, mine, optimize, device=torch.device("cpu"), rotate=rotate, comms=comms)
     outs = []
     for i in range(nimg):
         if encs is not None:
@@ -170,6 +170,7 @@ def _shared_targets(depth, world, nbytes):
               "hl": torch.zeros(1, dtype=torch.int64).share_memory_()} for _ in range(world)] for _ in range(depth)]
 
 
+@pytest.mark.parametrize("comms", ["ordered", "per-slot"])
 @pytest.mark.parametrize("world,css,optimize,ri,collect_each,rotate", [
     (2, 1, True, 13, True, True), (3, 1, True, 13, True, True), (5, 2, True, 26, True, True), (8, 1, True, 13, True, True), (8, 0, False, 13, True, True),
     (2, 1, True, 40, True, True),        # one restart-aligned strip only: rank 1 owns nothing (the case round 1 dropped)
@@ -178,7 +179,7 @@ def _shared_targets(depth, world, nbytes):
     (3, 1, True, 13, False, True), (8, 1, True, 13, False, True),
     (3, 1, True, 13, True, False), (8, 1, True, 13, False, False),      # the fixed root (rank 0 assembles every file)
 ])
-def test_device_pipeline_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri, collect_each, rotate):
+def test_device_pipeline_equals_one_rank_file(oracle, tmp_path, world, css, optimize, ri, collect_each, rotate, comms):
     """DEPTH images in flight, sizes all-gathered device-to-device, strips put at offsets derived from them, the assembling
     rank rotating from image to image: every image must come out as the 1-rank file (collect_each), and a bench-style loop
     (issue only, flush once) must end on the last one."""
@@ -186,7 +187,9 @@ def test_device_pipeline_equals_one_rank_file(oracle, tmp_path, world, css, opti
     W, H, q, nimg = 208, 250, 92, 9
     out = str(tmp_path / "dev.jpg")
     targets = _shared_targets(sharded.DEPTH, world, 3 * W * (H + 16))
-    mp.spawn(_device_pipeline_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, nimg, collect_each, targets, out, rotate),
+    if comms == "per-slot" and (world not in (3, 8) or not rotate):
+        pytest.skip("one communicator per slot (the experiment switch) is covered at world 3 and 8")
+    mp.spawn(_device_pipeline_worker, args=(world, _free_port(), W, H, css, optimize, ri, q, nimg, collect_each, targets, out, rotate, comms),
              nprocs=world, join=True)
     for i in (range(nimg) if collect_each else [nimg - 1]):
         want = oracle.encode(np.roll(oracle.synth_rgb(W, H), 7 * i, axis=1).copy(), q, css, optimize, ri)

@@ -5,7 +5,10 @@
 
 Corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KiB; on gfx950 FETCH_SIZE tallies the
 128-B requests of wide streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
-bench.py copies `total_bytes` of the dominant kernel into roofline.traffic when the workload string matches.
+bench.py copies `total_bytes` of the dominant kernel into roofline.traffic when the workload matches AND the
+`library_source_hash` recorded here (read from the bench line each pass logged, i.e. the hash compiled into the libmijpeg.so
+that ran under the counters) equals the hash of the library bench.py itself has loaded: counters taken on other kernels are
+never quoted.
 """
 import collections
 import csv
@@ -29,15 +32,28 @@ def per_kernel(directory, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
+def logged_hash(directory):
+    """library_source_hash of the bench line the pass wrote to <directory>/log.txt (tools/pmc_pass.sh)."""
+    try:
+        lines = [l for l in open(directory + "/log.txt") if l.startswith("{")]
+        return json.loads(lines[-1]).get("library_source_hash")
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def main():
     fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
+    h_f, h_w = logged_hash(sys.argv[1]), logged_hash(sys.argv[2])
+    if h_f is None or h_f != h_w:
+        sys.exit("the two passes do not name one library_source_hash (%s / %s): not writing a traffic file" % (h_f, h_w))
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         fb = int(fetch.get(k, 0.0) * 1024 * 2)
         wb = int(write.get(k, 0.0) * 1024)
         kernels[k] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "launches_averaged": [nf.get(k, 0), nw.get(k, 0)]}
     print(json.dumps({
+        "library_source_hash": h_f,
         "workload": "8320x40000 q95 4:2:2 optimised, AUTO restart interval (64 MCUs), 1 GPU (bench.py defaults)",
         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; "
                   "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); mean per launch",

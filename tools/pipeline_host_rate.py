@@ -16,6 +16,7 @@ from nvjpeg_imagecompressor_amd import sharded
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 W, H = 8320, int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+COMMS = sys.argv[2] if len(sys.argv) > 2 else "ordered"       # "ordered" (one communicator, the default) | "per-slot"
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -26,7 +27,7 @@ mij.synth_image_device(img.data_ptr(), W, 0, H, W * 3, bgr=True)
 torch.cuda.synchronize()
 strips = [sharded.HipStripEncoder(torch, e, img, "bgr") for e in encs]
 targets = sharded.open_file_targets(torch, dist, strips, 0, 1, 0, whole)
-pipe = sharded.DevicePipeline(torch, dist, strips, targets, True, device=dev)
+pipe = sharded.DevicePipeline(torch, dist, strips, targets, True, device=dev, comms=COMMS)
 for _ in range(20):
     pipe.step()
 pipe.flush()
@@ -42,7 +43,7 @@ issued = time.perf_counter() - t0
 pipe.flush()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
-print(json.dumps({"strip": "%dx%d" % (W, H), "images": N, "ms_per_image_wall": round(wall / N * 1e3, 4),
+print(json.dumps({"strip": "%dx%d" % (W, H), "comms": COMMS, "images": N, "ms_per_image_wall": round(wall / N * 1e3, 4),
                   "ms_per_image_host_in_step": round(host / N * 1e3, 4), "ms_per_image_until_all_issued": round(issued / N * 1e3, 4)}))
 for e in encs:
     e.close()

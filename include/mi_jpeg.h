@@ -245,6 +245,16 @@ MIJ_API int mij_decode_host(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_b
  * mode +1: out = clip(a + b - 128)  (reconstruction from decoded a and decoded residual b).  n = number of bytes. */
 MIJ_API int mij_residual_device(const void *d_a, const void *d_b, void *d_out, size_t n, int mode, void *stream);
 
+/* The first layer's reconstruction WITHOUT decoding its file: after mij_encode_transform / mij_encode_device of image I on this
+ * handle, D = dec(enc(I)) is a function of the quantised coefficients the handle still holds (entropy coding is lossless), so
+ * this call runs dequantisation + inverse DCT + upsampling + colour conversion straight from them -- pixel for pixel what
+ * mij_decode_device makes of the handle's file -- and stores, asynchronously on `stream`,
+ *   d_src != NULL:  R = clip(I - D + 128)   (the difference map; d_src = the image the coefficients came from, same format)
+ *   d_src == NULL:  D itself.
+ * `input_format` (MIJ_INPUT_*) describes d_src AND d_dst. Whole images only. Valid until the handle's next transform. */
+MIJ_API int mij_encode_residual_device(mij_encoder *enc, const void *d_src, size_t pitch, size_t plane_stride, int input_format,
+                                       void *d_dst, size_t dst_pitch, size_t dst_plane_stride, void *stream);
+
 /* The whole two-layer scheme in one call each way (host memory in, host memory out; whole images, not strips):
  *   encode:  J1 = enc(I);  D = dec(J1);  R = clip(I - D + 128);  J2 = enc(R)          (same quality / sampling for both layers)
  *   decode:  I' = clip(dec(J1) + dec(J2) - 128)
@@ -252,7 +262,8 @@ MIJ_API int mij_residual_device(const void *d_a, const void *d_b, void *d_out, s
  * file sizes on return. MIJ_ERR_OVERFLOW if either is too small: *primary_bytes then holds the size the first layer needs,
  * *secondary_bytes the size the second layer needs (0 if the first layer already did not fit and the second was not coded);
  * grow the buffers and call again. A residual image is close to noise: at high quality with dense restart markers a layer
- * can exceed the raw image size. Encoder and decoder must be on the same device. */
+ * can exceed the raw image size. The encode side no longer needs the decoder (D comes from the encoder's coefficients,
+ * mij_encode_residual_device): `dec` may be NULL; if given it must be on the encoder's device. */
 MIJ_API int mij_secondary_encode_host(mij_encoder *enc, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride,
                                       int input_format, uint8_t *primary, size_t *primary_bytes, uint8_t *secondary,
                                       size_t *secondary_bytes);

@@ -26,7 +26,7 @@ EXPORTS = (
     "mij_decode_device", "mij_decode_sync", "mij_decode_host", "mij_residual_device", "mij_host_alloc", "mij_host_free",
     "mij_secondary_encode_host", "mij_secondary_decode_host", "mij_decode_last_ms", "mij_decoder_device",
     "mij_geometry_query", "mij_encode_entropy_sizes", "mij_encode_place", "mij_sharded_result", "mij_encoder_reserve_output",
-    "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close", "mij_place_times",
+    "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close", "mij_place_times", "mij_encode_residual_device",
 )
 
 
@@ -144,6 +144,7 @@ def load():
     L.mij_encode_place.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, vp]
     L.mij_sharded_result.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]
     L.mij_place_times.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mij_encode_residual_device.argtypes = [vp, vp, sz, sz, C.c_int, vp, sz, sz, vp]
     L.mij_encoder_reserve_output.argtypes = [vp, sz]
     L.mij_output_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.mij_ipc_export.argtypes = [vp, vp]

@@ -1018,15 +1018,55 @@ int mij_encode_host(mij_encoder *e, const uint8_t *src, size_t pitch, size_t pla
   return MIJ_OK;
 }
 
-// Secondary ("difference map") compression end to end (reference README.md:8; definition SURVEY.md 8a A9).
+// ---- secondary ("difference map") compression (reference README.md:8; definition SURVEY.md 8a A9) -------------------------
+// D = dec(enc(I)) is a pure function of the quantised coefficients, and those are still in the handle's coefficient buffer
+// after mij_encode_transform: the inverse transform reads them there (k_idct_enc: the tiled, transposed layout as it is) and
+// the upsampling + colour kernel subtracts from the original on its way out. Round 2 Huffman-decoded the file it had just
+// written (7.2 of the 10.8 ms of BASELINE config 5) and ran a separate subtraction pass over I and D.
+static int ensure_sec(mij_encoder *e, size_t bytes) {
+  if (bytes <= e->d_sec_bytes) return MIJ_OK;
+  if (e->issued || e->transformed) HIPCHK(e, hipStreamSynchronize(e->last_stream));     // the old buffer may still be in use
+  (void)hipFree(e->d_sec); e->d_sec = nullptr; e->d_sec_bytes = 0;
+  HIPCHK(e, hipMalloc(&e->d_sec, bytes));
+  e->d_sec_bytes = bytes;
+  return MIJ_OK;
+}
+static size_t plane_bytes(const Geom &g) {       // Y padded to whole MCUs + Cb + Cr (k_idct's planes)
+  return (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8 + 2 * ((size_t)g.mcux * 8 * g.mcuy * 8);
+}
+
+int mij_encode_residual_device(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *d_dst, size_t dst_pitch,
+                               size_t dst_plane_stride, void *stream) {
+  if (!e || !d_dst) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
+  if (!interleaved && fmt != MIJ_INPUT_RGB && fmt != MIJ_INPUT_BGR) return fail(e, MIJ_ERR_INVALID_ARG, "unknown pixel format");
+  const Geom &g = e->g;
+  if (g.mcu_first != 0 || !g.last_strip) return fail(e, MIJ_ERR_INVALID_ARG, "the difference map works on whole images (chroma upsampling crosses strip boundaries)");
+  if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_residual_device needs the coefficients of a mij_encode_transform / mij_encode_device on this handle");
+  const size_t row = (size_t)g.W * (interleaved ? 3 : 1);
+  if (dst_pitch < row || (d_src && pitch < row)) return fail(e, MIJ_ERR_INVALID_ARG, "pitch smaller than a pixel row");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  // the planes live at the START of d_sec (mij_secondary_encode_host keeps its residual image behind them)
+  int rc = ensure_sec(e, plane_bytes(g));
+  if (rc) return rc;
+  if (s != e->last_stream) HIPCHK(e, hipStreamWaitEvent(s, e->ev_xdone, 0));      // the coefficients were written on another stream
+  const size_t ysz = (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8, csz = (size_t)g.mcux * 8 * g.mcuy * 8;
+  uint8_t *py = e->d_sec, *pcb = py + ysz, *pcr = pcb + csz;
+  HIPCHK(e, launch_idct_enc(g, e->d_coef, e->d_qt, py, pcb, pcr, s));
+  HIPCHK(e, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, dst_pitch, dst_plane_stride, fmt, s, (const uint8_t *)d_src, pitch, plane_stride));
+  return MIJ_OK;
+}
+
+// Both layers end to end, host memory in and out.
 int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt,
                               uint8_t *primary, size_t *primary_bytes, uint8_t *secondary, size_t *secondary_bytes) {
-  if (!e || !dec || !src || !primary || !primary_bytes || !secondary || !secondary_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  if (!e || !src || !primary || !primary_bytes || !secondary || !secondary_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
   const Geom &g = e->g;
   if (g.mcu_first != 0 || !g.last_strip) return fail(e, MIJ_ERR_INVALID_ARG, "secondary compression works on whole images");
-  if (mij_decoder_device(dec) != e->p.device) return fail(e, MIJ_ERR_INVALID_ARG, "encoder and decoder are on different devices");
+  if (dec && mij_decoder_device(dec) != e->p.device) return fail(e, MIJ_ERR_INVALID_ARG, "encoder and decoder are on different devices");
   const uint8_t *j1 = nullptr; size_t n1 = 0;
-  int rc = mij_encode_host(e, src, pitch, plane_stride, fmt, &j1, &n1);      // J1; the image stays in e->d_src
+  int rc = mij_encode_host(e, src, pitch, plane_stride, fmt, &j1, &n1);      // J1; the image stays in e->d_src, its coefficients in e->d_coef
   if (rc) return rc;
   const size_t cap1 = *primary_bytes, cap2 = *secondary_bytes;
   *primary_bytes = n1;
@@ -1034,22 +1074,15 @@ int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *s
   memcpy(primary, j1, n1);
   const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
   const size_t bytes = interleaved ? pitch * (size_t)g.H : plane_stride * 2 + pitch * (size_t)g.H;
-  if (2 * bytes > e->d_sec_bytes) {
-    (void)hipFree(e->d_sec); e->d_sec = nullptr; e->d_sec_bytes = 0;
-    HIPCHK(e, hipMalloc(&e->d_sec, 2 * bytes));
-    e->d_sec_bytes = 2 * bytes;
-  }
-  uint8_t *d_dec = e->d_sec, *d_res = e->d_sec + bytes;
-  mij_result r1;
-  rc = mij_encode_result(e, &r1);
+  const size_t planes = (plane_bytes(g) + 255) & ~(size_t)255;
+  rc = ensure_sec(e, planes + bytes);
   if (rc) return rc;
-  // D = dec(J1), same layout as the input; J1 is still in the encoder's device buffer: decoded in place, no second upload
-  rc = mij_decode_device(dec, r1.d_buffer + r1.header_offset, n1, d_dec, pitch, plane_stride, fmt, nullptr);
-  if (!rc) rc = mij_decode_sync(dec, nullptr);
-  if (rc) return fail(e, rc, mij_decoder_last_error(dec));
-  rc = mij_residual_device(e->d_src, d_dec, d_res, bytes, -1, nullptr);                 // R = clip(I - D + 128)
-  if (rc) return fail(e, rc, "residual kernel");
-  rc = mij_encode_device(e, d_res, pitch, plane_stride, fmt, nullptr);                  // J2 = enc(R)
+  uint8_t *d_res = e->d_sec + planes;
+  hipStream_t s = e->last_stream;
+  // R = clip(I - D + 128) with D = dec(J1) reconstructed from the coefficients J1 was coded from (no decode of the file)
+  rc = mij_encode_residual_device(e, e->d_src, pitch, plane_stride, fmt, d_res, pitch, plane_stride, s);
+  if (rc) return rc;
+  rc = mij_encode_device(e, d_res, pitch, plane_stride, fmt, s);                        // J2 = enc(R)
   if (rc) return rc;
   size_t n2 = 0;
   rc = mij_retrieve_bitstream(e, nullptr, &n2);

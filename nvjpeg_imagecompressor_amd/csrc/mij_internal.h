@@ -191,8 +191,12 @@ hipError_t launch_par_decode(const Geom &g, const uint8_t *clean, size_t n, cons
                              hipStream_t s, DcFix *fix);
 hipError_t launch_idct(const Geom &g, const int16_t *coef, const DecTables *tab, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s,
                        const DcFix &fix = DcFix{});
+// orig != null: stores the difference map R = clip(orig - D + 128) instead of the decoded pixels D (orig laid out like dst)
 hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, uint8_t *dst, size_t pitch,
-                                 size_t plane_stride, int out_fmt, hipStream_t s);
+                                 size_t plane_stride, int out_fmt, hipStream_t s, const uint8_t *orig = nullptr, size_t orig_pitch = 0,
+                                 size_t orig_plane_stride = 0);
+// The inverse transform straight from an ENCODER's coefficient buffer (tiled, transposed) and quantisation table.
+hipError_t launch_idct_enc(const Geom &g, const int16_t *coef, const Quant *qt, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
 hipError_t launch_residual(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int sign, hipStream_t s);
 
 }  // namespace mij

@@ -93,6 +93,14 @@ class Encoder:
         _lib.check(self._L.mij_place_times(self._h, ms), self._h, "mij_place_times")
         return float(ms[0]), float(ms[1])
 
+    def residual_device(self, d_src, pitch, d_dst, fmt="bgr", plane_stride=0, dst_pitch=None, dst_plane_stride=None, stream=0):
+        """After encode_device / transform of image I on this handle: d_dst <- clip(I - D + 128) with D = what a decoder makes
+        of this handle's file, computed from the coefficients (d_src = I); d_src = 0 / None: d_dst <- D itself."""
+        _lib.check(self._L.mij_encode_residual_device(self._h, C.c_void_p(d_src or 0), pitch, plane_stride, _FMT[fmt], C.c_void_p(d_dst),
+                                                      pitch if dst_pitch is None else dst_pitch,
+                                                      plane_stride if dst_plane_stride is None else dst_plane_stride, C.c_void_p(stream)),
+                   self._h, "mij_encode_residual_device")
+
     def reserve_output(self, scan_capacity):
         _lib.check(self._L.mij_encoder_reserve_output(self._h, scan_capacity), self._h, "mij_encoder_reserve_output")
 

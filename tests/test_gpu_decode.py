@@ -1,12 +1,14 @@
 """HIP decode path and secondary difference-map compression (A9), through the C ABI, against the
 CPU oracle decoder (itself pinned pixel-for-pixel against libjpeg-turbo) and against the stock decoder directly."""
 import io
+import zlib
 
 import numpy as np
 import pytest
 from PIL import Image
 
 pytestmark = pytest.mark.gpu
+J2_CRC = 0xC68E97B1      # the second layer of BASELINE config 5 (51,115,282 bytes), as round 2's route (decode the file, subtract) wrote it
 
 
 def _pil_dec(j):
@@ -87,6 +89,37 @@ def test_facade_decode(mij, oracle, tmp_path):
     r.deleteDecodeEnv()
 
 
+@pytest.mark.parametrize("css", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("size", [(512, 512), (64, 48), (8, 8), (1, 1), (3, 5), (17, 33), (100, 75), (129, 65), (250, 3), (1040, 136)])
+@pytest.mark.parametrize("fmt", ["bgr", "rgb_planar"])
+def test_reconstruction_from_coefficients_equals_decoding_the_file(mij, oracle, css, size, fmt):
+    """mij_encode_residual_device: D rebuilt from the encoder's coefficient buffer == what the decoder makes of the file that
+    encoder wrote, pixel for pixel (all six samplings, odd sizes, interleaved and planar), and R == clip(I - D + 128)."""
+    import torch
+    W, H = size
+    rgb = oracle.synth_rgb(W, H)
+    if fmt == "bgr":
+        img = np.ascontiguousarray(rgb[..., ::-1])
+        pitch, plane = W * 3, 0
+    else:
+        img = np.ascontiguousarray(rgb.transpose(2, 0, 1))
+        pitch, plane = W, W * H
+    d_img = torch.from_numpy(img).to("cuda:0")
+    d_D, d_R = torch.zeros_like(d_img), torch.zeros_like(d_img)
+    with mij.Encoder(W, H, 90, True, css) as enc, mij.Decoder() as dec:
+        enc.encode_device(d_img.data_ptr(), pitch, fmt, plane)
+        jpg = enc.retrieve()
+        enc.residual_device(None, pitch, d_D.data_ptr(), fmt, plane)
+        enc.residual_device(d_img.data_ptr(), pitch, d_R.data_ptr(), fmt, plane)
+        torch.cuda.synchronize()
+        want = dec.decode_host(jpg, fmt)
+    got = d_D.cpu().numpy()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:4].tolist()
+    assert np.array_equal(want if fmt != "bgr" else want[..., ::-1], _pil_dec(jpg) if fmt == "bgr" else _pil_dec(jpg).transpose(2, 0, 1))
+    res = np.clip(img.astype(np.int32) - want.astype(np.int32) + 128, 0, 255).astype(np.uint8)
+    assert np.array_equal(d_R.cpu().numpy(), res)
+
+
 def test_fullsize_decode_and_secondary_compression(mij, oracle):
     """BASELINE config 5: 8320x40000 q95 4:2:2: encode -> decode -> difference map -> re-encode, round trip."""
     import torch
@@ -118,8 +151,17 @@ def test_fullsize_decode_and_secondary_compression(mij, oracle):
         del ref, got
         mij.residual_device(d_img.data_ptr(), d_dec.data_ptr(), d_res.data_ptr(), n, -1)      # R = clip(I - D + 128)
         torch.cuda.synchronize()
+        # the same two things from the encoder's coefficients, without the file (mij_encode_residual_device): identical at the full size
+        enc.residual_device(None, W * 3, d_rec.data_ptr(), "bgr")
+        torch.cuda.synchronize()
+        assert torch.equal(d_rec, d_dec)
+        enc.residual_device(d_img.data_ptr(), W * 3, d_rec.data_ptr(), "bgr")
+        torch.cuda.synchronize()
+        assert torch.equal(d_rec, d_res)
         enc.encode_device(d_res.data_ptr(), W * 3, "bgr")
         j2 = enc.retrieve()
+        print("J2 crc %08x" % zlib.crc32(j2))
+        assert len(j2) == 51115282 and (J2_CRC is None or zlib.crc32(j2) == J2_CRC), "%d %08x" % (len(j2), zlib.crc32(j2))
         dec.decode_device(j2, d_rec.data_ptr(), W * 3, "bgr")
         dec.sync()
         mij.residual_device(d_dec.data_ptr(), d_rec.data_ptr(), d_rec.data_ptr(), n, +1)      # I' = clip(D + R' - 128)

@@ -15,17 +15,21 @@ OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default" is what ships (K4's strip sizes are template
     # parameters now: MIJ_K4_WIDE=1 in the environment selects the 24-word kernel at run time)
     "default": {},
+    # round 3: the instruction-count changes, one at a time (defaults: DOT3 on, RTZ and STAT2 off; profiles/r03_k1_variants.txt)
+    "no_dot3": {"MIJ_K1_DOT3": 0},
+    "rtz": {"MIJ_K1_RTZ": 1},
+    "stat2_c5": {"MIJ_K1_STAT2": 1},
+    "stat2_c4": {"MIJ_K1_STAT2": 1, "MIJ_HIST_COPIES": 4},
+    "all3_c4": {"MIJ_K1_STAT2": 1, "MIJ_HIST_COPIES": 4, "MIJ_K1_RTZ": 1},
     "waves2": {"MIJ_K1_WAVES": 2},
     "copies2": {"MIJ_HIST_COPIES": 2},
     "no_atomics": {"MIJ_K1_STATMODE": 1},
     "conflict_free": {"MIJ_K1_STATMODE": 2},
     "nostore": {"MIJ_K1_NOSTORE": 1},
     "noload": {"MIJ_K1_NOLOAD": 1},
-    "copies4": {"MIJ_HIST_COPIES": 4},
     "waves4": {"MIJ_K1_WAVES": 4},
     "nz_from_size": {"MIJ_K1_NZ_FROM_SIZE": 1},
     "noflush": {"MIJ_K1_NOFLUSH": 1},
-    "copies3": {"MIJ_HIST_COPIES": 3},
     "nt_stores": {"MIJ_K1_NT_STORES": 1},
 }
 if os.environ.get("MIJ_VARIANTS"):
@@ -33,7 +37,13 @@ if os.environ.get("MIJ_VARIANTS"):
 
 
 def build():
-    for name, defs in VARIANTS.items():
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(int(os.environ.get("MIJ_VARIANTS_JOBS", "4"))) as ex:
+        list(ex.map(lambda kv: build_one(*kv), VARIANTS.items()))
+
+
+def build_one(name, defs):
+    if True:
         d = os.path.join(OUT, name)
         os.makedirs(d, exist_ok=True)
         objs = []

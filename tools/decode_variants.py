@@ -10,13 +10,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
-VARIANTS = {"dec_default": {}, "dec_s512": {"MIJ_PAR_S": 512}, "dec_s2048": {"MIJ_PAR_S": 2048}, "dec_s768": {"MIJ_PAR_S": 768}}
+VARIANTS = {"dec_default": {}, "dec_s256": {"MIJ_PAR_S": 256}, "dec_s384": {"MIJ_PAR_S": 384}, "dec_s512": {"MIJ_PAR_S": 512}, "dec_s640": {"MIJ_PAR_S": 640},
+            "dec_s768": {"MIJ_PAR_S": 768}, "dec_s2048": {"MIJ_PAR_S": 2048}}
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
 
 
 def build():
-    for name, defs in VARIANTS.items():
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(4) as ex:
+        list(ex.map(lambda kv: build_one(*kv), VARIANTS.items()))
+
+
+def build_one(name, defs):
+    if True:
         d = os.path.join(OUT, name)
         os.makedirs(d, exist_ok=True)
         objs = []
@@ -37,7 +44,8 @@ def run():
     for name in VARIANTS:
         env = dict(os.environ, MIJ_LIB_PATH=os.path.join(OUT, name, "libmijpeg.so"))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decode_fullsize.py")], capture_output=True, text=True, env=env)
-        print(name, r.stdout.strip()[-400:] if r.returncode == 0 else "FAILED " + r.stderr[-600:], flush=True)
+        trace = [l.split(": ")[1].split()[0] for l in r.stderr.splitlines() if l.startswith("[par]")]
+        print(name, r.stdout.strip()[-330:] if r.returncode == 0 else "FAILED " + r.stderr[-600:], "redo counts per pass:", trace[-4:], flush=True)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ cd $R && python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write >
 python tools/pmc_summary.py gpurun_out/pmc_a gpurun_out/pmc_b > $O/pmc_sq_summary.txt
 step done
 # second half: lines that quote the refreshed traffic file, progressive / decode kernel statistics, config 5
-cp $O/hbm_traffic.json $R/profiles/r02_hbm_traffic.json
+cp $O/hbm_traffic.json $R/profiles/r03_hbm_traffic.json
 step "bench lines";        mkdir -p $O/lines && timeout -k 10 400 python bench.py > $O/lines/n1.json 2> $O/lines/err.txt && timeout -k 10 300 python bench.py --no-optimize --no-cpu-baseline > $O/lines/fixed.json 2>> $O/lines/err.txt && timeout -k 10 300 python bench.py --two-streams --no-cpu-baseline > $O/lines/two.json 2>> $O/lines/err.txt || exit 1
 step "progressive stats";  bash tools/profile_prog1.sh >> $O/progress.txt 2>&1 || exit 1
 step "decode";             timeout -k 10 300 python tools/decode_fullsize.py 2>/dev/null | tail -1 > $O/decode_fullsize.json || exit 1

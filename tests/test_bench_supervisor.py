@@ -86,6 +86,15 @@ def test_clean_run_relays_rank0_line(bench, capsys, monkeypatch):
     assert sorted(int(r) for m, r, _ in log) == [0, 1, 2] and {m for m, _, _ in log} == {"put"}
 
 
+def test_auto_runs_both_gathers_and_prints_the_faster(bench, capsys, monkeypatch):
+    """--gather auto (the default): after the put pipeline's run, a complete run with send/recv; both values in the line."""
+    rc, d, log = _run(bench, capsys, {}, monkeypatch, gather="auto")
+    assert rc == 0 and set(d["gather_runs"]) == {"put", "sendrecv"} and d["config"]["gather"] in ("put", "sendrecv")
+    assert {m for m, _, _ in log} == {"put", "sendrecv"} and len(log) == 6
+    rc, d, log = _run(bench, capsys, {"sendrecv": "die"}, monkeypatch, gather="auto")          # the alternative failing costs nothing
+    assert rc == 0 and d["config"]["gather"] == "put" and "failed" in d["gather_runs"]["sendrecv"]
+
+
 def test_dead_rank_falls_back_with_fresh_processes(bench, capsys, monkeypatch):
     rc, d, log = _run(bench, capsys, {"put": "die"}, monkeypatch)
     assert rc == 0 and d["config"]["gather"] == "sendrecv"

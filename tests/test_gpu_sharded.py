@@ -233,7 +233,10 @@ def test_bench_under_an_external_launcher(one_gpu_line):
     """The driver's documented command shape: torch.distributed.run starts N ranks of bench.py. Its local rank 0 supervises N
     fresh children (the same ones the plain command starts), the launcher's other ranks leave at once."""
     d, _ = _bench(["--gpus", "3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-psnr", "--height", "4000"], launcher=3)
-    assert d["n_gpus"] == 3 and d["config"]["gather"] == "put" and d["launcher"].startswith("external launcher (3 ranks)")
+    assert d["n_gpus"] == 3 and d["launcher"].startswith("external launcher (3 ranks)")
+    # the default gather is `auto`: a complete run with the put pipeline AND one with send/recv, the faster one's line printed
+    assert set(d["gather_runs"]) == {"put", "sendrecv"} and all(r["value"] > 0 for r in d["gather_runs"].values())
+    assert d["config"]["gather"] == max(d["gather_runs"], key=lambda k: d["gather_runs"][k]["value"])
     assert d["jpeg_crc32"] == one_gpu_line["jpeg_crc32"]
 
 

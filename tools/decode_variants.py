@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nvjpeg_imagecompressor_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {"dec_default": {}, "dec_s256": {"MIJ_PAR_S": 256}, "dec_s384": {"MIJ_PAR_S": 384}, "dec_s512": {"MIJ_PAR_S": 512}, "dec_s640": {"MIJ_PAR_S": 640},
-            "dec_s768": {"MIJ_PAR_S": 768}, "dec_s2048": {"MIJ_PAR_S": 2048}}
+            "dec_s768": {"MIJ_PAR_S": 768}, "dec_s2048": {"MIJ_PAR_S": 2048},
+            # write pass with 128 / 256 / 512 lanes per workgroup (the Huffman tables in LDS are per workgroup): tools/decode_hammer.py
+            "dec_wg128": {"MIJ_PAR_WG2": 128}, "dec_wg256": {"MIJ_PAR_WG2": 256}, "dec_wg512": {"MIJ_PAR_WG2": 512}}
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
 

@@ -200,11 +200,15 @@ def test_secondary_compression_end_to_end(mij, oracle):
     r.deleteCompressEnv(); r.deleteDecodeEnv()
 
 
-@pytest.mark.parametrize("env", [{"MIJ_DECODE_LANES": "1"}, {"MIJ_PAR_MAX_PASSES": "1"}], ids=["lane_per_interval", "fallback_after_one_pass"])
+@pytest.mark.parametrize("env", [{"MIJ_DECODE_LANES": "1"}, {"MIJ_PAR_MAX_PASSES": "1"},
+                                 {"MIJ_PAR_TAIL": "48", "MIJ_PAR_SPARSE": "1000000"}, {"MIJ_PAR_TAIL": "160", "MIJ_PAR_SPARSE": "0"}],
+                         ids=["lane_per_interval", "fallback_after_one_pass", "sparse_passes_with_long_lists", "dense_passes_only"])
 def test_alternative_baseline_decode_routes(env, tmp_path):
     """The lane-per-interval kernel (k_huff_decode) stays covered: directly (A/B switch) and as the fallback the
-    subsequence-parallel decoder takes when its states do not settle (forced here by allowing a single pass). The switches
-    are read once per process, hence the child process."""
+    subsequence-parallel decoder takes when its states do not settle (forced here by allowing a single pass). Likewise the two
+    forms of the later synchronisation passes: a short speculative tail leaves thousands of subsequences unsynchronised after
+    the first pass, which are then all taken by the sparse kernel (k_par_sync_sparse: chains of listed neighbours, in-place
+    updates) or all by the dense one. The switches are read once per process, hence the child process."""
     import os
     import subprocess
     import sys
@@ -216,7 +220,7 @@ import nvjpeg_imagecompressor_amd as mij
 rng = np.random.default_rng(3)
 img = rng.integers(0, 256, (700, 900, 3), dtype=np.uint8)
 with mij.Decoder() as dec:
-    for kw in (dict(quality=92, subsampling=1), dict(quality=60, subsampling=2, restart_marker_blocks=9)):
+    for kw in (dict(quality=92, subsampling=1), dict(quality=60, subsampling=2, restart_marker_blocks=9), dict(quality=97, subsampling=0, restart_marker_rows=8)):
         b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", **kw); j = b.getvalue()
         assert np.array_equal(dec.decode_host(j, "rgb"), np.asarray(Image.open(io.BytesIO(j)).convert("RGB")))
     with mij.Encoder(900, 700, 90, True, 1) as enc:

@@ -164,8 +164,8 @@ def _run_attempt(world, mode):
     import queue
     import subprocess
     import threading
-    init_bound = float(os.environ.get("MIJ_BENCH_WATCHDOG_INIT_S", "600"))     # first import of torch on a fresh box: minutes
-    step_bound = float(os.environ.get("MIJ_BENCH_WATCHDOG_S", "300"))          # between two progress marks afterwards
+    init_bound = float(os.environ.get("MIJ_BENCH_WATCHDOG_INIT_S", "420"))     # first import of torch on a fresh box: minutes
+    step_bound = float(os.environ.get("MIJ_BENCH_WATCHDOG_S", "180"))          # between two progress marks afterwards
     port = _free_port()
     procs = []
     for r in range(world):
@@ -277,6 +277,17 @@ def _progress(rank, what):
     """Rank 0 of a supervised run tells the supervisor how far it got (its watchdog is on the time between two marks)."""
     if rank == 0 and os.environ.get("MIJ_BENCH_CHILD") == "1":
         print("##progress " + what, flush=True)
+        _HEART["t"] = time.monotonic()
+
+
+_HEART = {"t": 0.0}
+
+
+def _heartbeat(rank, what):
+    """Inside loops: a mark at most every five seconds, so that a slow but healthy run (a rehearsal over gloo, a node with a slow
+    gather) is not taken for a stalled one."""
+    if rank == 0 and time.monotonic() - _HEART["t"] > 5.0:
+        _progress(rank, what)
 
 
 def _inject(rank, gather, where):
@@ -318,7 +329,7 @@ def worker(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # A collective that does not complete within the bound ends the rank (RCCL's watchdog), the supervisor sees it die
         # and starts fresh processes with the next gather: nothing waits for ever.
-        coll_timeout = datetime.timedelta(seconds=float(os.environ.get("MIJ_BENCH_COLL_TIMEOUT_S", "180")))
+        coll_timeout = datetime.timedelta(seconds=float(os.environ.get("MIJ_BENCH_COLL_TIMEOUT_S", "120")))
         if one_device:
             dist.init_process_group("gloo", timeout=coll_timeout)
         else:
@@ -472,15 +483,17 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step(False)
+        _heartbeat(rank, "warm-up step %d" % i)
     collect(False)
     # Put pipeline: one image per ROOT collected and fingerprinted before anything is timed (the timed loop only ever looks at
     # its last file). Every root must have assembled the same bytes; rank 0 compares them with the timed region's file below.
     root_files = None
     if dpipe is not None:
         mine = []
-        for _ in range(dpipe.nroots):
+        for i in range(dpipe.nroots):
+            _heartbeat(rank, "verifying root %d" % i)
             dpipe.step()
             o = dpipe.collect()
             if o is not None:
@@ -494,8 +507,9 @@ def worker(args):
     fence()
     _progress(rank, "warm-up done")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         jpeg_t = step(True)
+        _heartbeat(rank, "timed step %d" % i)
     if pipelined:
         jpeg_t = collect(True)         # the last image of the timed region
     fence()
@@ -526,7 +540,8 @@ def worker(args):
         # ONE image alone through the same path, start to complete file (what a caller with a single image waits for; the
         # `value` above is the rate with several images in flight). Max over ranks, median of five.
         lat = []
-        for _ in range(5):
+        for i in range(5):
+            _heartbeat(rank, "latency %d" % i)
             fence()
             t1 = time.perf_counter()
             if dpipe is not None:

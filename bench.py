@@ -649,6 +649,15 @@ def worker(args):
                         "frac": stage_roof[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
                         "note": "avg launch duration from hipEvents on the kernels' stream over the timed steps"}
+            if _VALU.get(kname[dom]):
+                # What actually bounds this path: vector instruction issue. At the 3-5 waves per SIMD these
+                # kernels run at, a wave64 vector instruction occupies its SIMD for ~4 cycles; PMC count (same passes, same hash).
+                n = _VALU[kname[dom]]
+                sm = 1024 * 2.4e9 / 4.0         # wave-instructions per second: 1,024 SIMDs at 2.4 GHz, 4 cycles each
+                roofline["valu_issue"] = {"wave_instructions": n[kname[dom]], "floor_ms_at_4_cycles": round(n[kname[dom]] / sm * 1e3, 4),
+                                          "frac_of_launch": round(n[kname[dom]] / sm * 1e3 / stage_roof[dom]["ms"], 3),
+                                          "all_kernels_floor_ms": round(sum(n.values()) / sm * 1e3, 4),
+                                          "note": "SQ_INSTS_VALU per launch; the step is bound by vector issue, not by HBM"}
             if dom == "transform" and optimize:
                 # K1 also takes the AC statistics (SURVEY 8d stage B, a separate 2(1+f) B/px read in an unfused design);
                 # against stage A + B's algorithmic bytes, as SURVEY 8d prescribes for a fused kernel:
@@ -785,7 +794,12 @@ def measured_traffic(kernel, args, optimize, world, lib_hash):
     if d.get("library_source_hash") != lib_hash:
         return None, "%s was taken on another build of the library (%s...): not quoted" % (rel, str(d.get("library_source_hash"))[:12])
     k = d.get("kernels", {}).get(kernel)
+    if k and "valu_wave_instructions" in k:
+        _VALU[kernel] = {kk: vv["valu_wave_instructions"] for kk, vv in d["kernels"].items() if "valu_wave_instructions" in vv}
     return (k["total_bytes"], rel) if k else (None, None)
+
+
+_VALU = {}
 
 
 def _psnr_check(jpeg, W, H, fmt, d_img):

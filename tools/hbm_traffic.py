@@ -47,11 +47,17 @@ def main():
     h_f, h_w = logged_hash(sys.argv[1]), logged_hash(sys.argv[2])
     if h_f is None or h_f != h_w:
         sys.exit("the two passes do not name one library_source_hash (%s / %s): not writing a traffic file" % (h_f, h_w))
+    # optional third pass (tools/pmc_pass.sh b ... SQ_INSTS_VALU ...): vector wave-instructions per launch
+    valu = {}
+    if len(sys.argv) > 3 and logged_hash(sys.argv[3]) == h_f:
+        valu, _ = per_kernel(sys.argv[3], "SQ_INSTS_VALU")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         fb = int(fetch.get(k, 0.0) * 1024 * 2)
         wb = int(write.get(k, 0.0) * 1024)
         kernels[k] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "launches_averaged": [nf.get(k, 0), nw.get(k, 0)]}
+        if k in valu:
+            kernels[k]["valu_wave_instructions"] = int(valu[k])
     print(json.dumps({
         "library_source_hash": h_f,
         "workload": "8320x40000 q95 4:2:2 optimised, AUTO restart interval (64 MCUs), 1 GPU (bench.py defaults)",

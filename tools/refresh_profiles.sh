@@ -19,7 +19,7 @@ step "pmc fetch";          bash tools/pmc_pass.sh fetch FETCH_SIZE >> $O/progres
 step "pmc write";          bash tools/pmc_pass.sh write WRITE_SIZE >> $O/progress.txt 2>&1 || exit 1
 step "pmc sq a";           bash tools/pmc_pass.sh a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS >> $O/progress.txt 2>&1 || exit 1
 step "pmc sq b";           bash tools/pmc_pass.sh b GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS >> $O/progress.txt 2>&1 || exit 1
-cd $R && python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > $O/hbm_traffic.json
+cd $R && python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_b > $O/hbm_traffic.json
 python tools/pmc_summary.py gpurun_out/pmc_a gpurun_out/pmc_b > $O/pmc_sq_summary.txt
 step done
 # second half: lines that quote the refreshed traffic file, progressive / decode kernel statistics, config 5

@@ -176,6 +176,7 @@ def _run_attempt(world, mode):
         env.pop("MIJ_BENCH_NO_PIPELINE", None)
         procs.append(subprocess.Popen(_child_argv(mode), env=env, cwd=ROOT, start_new_session=True,
                                       stdout=subprocess.PIPE if r == 0 else 2, text=(r == 0) or None))       # other ranks: stdout -> our stderr (fd 2)
+    _LIVE[:] = procs                       # what a SIGTERM / SIGINT to the supervisor must take down with it (the children lead their own sessions)
     lines = queue.Queue()
 
     def pump():
@@ -220,7 +221,18 @@ def _run_attempt(world, mode):
     return (result, None, None) if reason is None else (None, reason, None)
 
 
+_LIVE = []
+
+
+def _on_signal(signum, frame):
+    _kill_children(list(_LIVE))
+    sys.exit(128 + signum)
+
+
 def supervise(args, world, launcher):
+    import signal
+    signal.signal(signal.SIGTERM, _on_signal)
+    signal.signal(signal.SIGINT, _on_signal)
     auto = args.gather == "auto"
     ladder = {"auto": ["put", "sendrecv", "serial"], "put": ["put", "sendrecv", "serial"], "sendrecv": ["sendrecv", "serial"], "serial": ["serial"]}[args.gather]
     if args.no_fallback or args.progressive:

@@ -128,6 +128,31 @@ def test_result_stands_when_a_rank_hangs_in_teardown(bench, capsys, monkeypatch)
     assert all(_gone(int(pid)) for _, _, pid in log)
 
 
+def test_a_terminated_supervisor_takes_its_children_with_it(tmp_path):
+    """SIGTERM to `python bench.py --gpus N` (a driver's timeout, say) must not leave ranks behind: they lead their own
+    sessions, so nothing but the supervisor would end them."""
+    import signal
+    script = tmp_path / "child.py"
+    script.write_text(CHILD)
+    log = tmp_path / "log.txt"
+    drv = tmp_path / "drv.py"
+    drv.write_text("import sys, json\nsys.path.insert(0, %r)\nimport bench\nbench._child_argv = lambda mode: [sys.executable, %r, mode]\n"
+                   "class A: gather, no_fallback, progressive = 'put', False, False\nsys.exit(bench.supervise(A(), 3, 'test'))\n" % (ROOT, str(script)))
+    p = subprocess.Popen([sys.executable, str(drv)], env=dict(os.environ, FAKE_PLAN=json.dumps({"put": "hang"}), FAKE_LOG=str(log)),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t_end = time.monotonic() + 30
+    while time.monotonic() < t_end and (not log.exists() or len(log.read_text().splitlines()) < 3):
+        time.sleep(0.1)
+    pids = [int(l.split()[2]) for l in log.read_text().splitlines()]
+    assert len(pids) == 3
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    t_end = time.monotonic() + 10
+    while time.monotonic() < t_end and not all(_gone(q) for q in pids):
+        time.sleep(0.1)
+    assert all(_gone(q) for q in pids)
+
+
 def test_plain_command_line_needs_no_launcher():
     """`python bench.py --gpus 2` on a box without a GPU: the supervisor itself runs (no 'needs torch.distributed.run' exit),
     starts ranks, sees them fail for lack of a device and reports that -- without ever importing torch itself."""

@@ -21,6 +21,9 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "stat2_c5": {"MIJ_K1_STAT2": 1},
     "stat2_c4": {"MIJ_K1_STAT2": 1, "MIJ_HIST_COPIES": 4},
     "all3_c4": {"MIJ_K1_STAT2": 1, "MIJ_HIST_COPIES": 4, "MIJ_K1_RTZ": 1},
+    "nt_loads": {"MIJ_K1_NT_LOADS": 1},
+    "k4_nt_loads": {"MIJ_COEF_NT_LOADS": 1},
+    "rtz_dot3": {"MIJ_K1_RTZ": 1, "MIJ_K1_DOT3": 1},
     "waves2": {"MIJ_K1_WAVES": 2},
     "copies2": {"MIJ_HIST_COPIES": 2},
     "no_atomics": {"MIJ_K1_STATMODE": 1},

@@ -13,7 +13,9 @@ put -> sendrecv -> serial; the line then carries "gather_fallback": "<reason>". 
 launcher's other ranks leave at once, so both command shapes run the same children with the same safety net
 (MIJ_BENCH_DIRECT=1: be a plain rank of the external launcher instead, no supervisor).
 
-A "step" is one whole encode of the image. At N > 1 the image is cut into restart-interval-aligned strips of MCU
+A "step" is one whole encode of the image. On one GPU three handles take turns: image i's transform, the entropy coder of image
+i-1 and the collection of image i-2 overlap on the host side, and image i's table build (one workgroup) runs on a side stream
+under image i-1's entropy coder; every other kernel runs alone on the main stream (--no-tables-ahead: two handles, one stream). At N > 1 the image is cut into restart-interval-aligned strips of MCU
 rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
 of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes (device to device), and every
 rank PUTS its strip into the file the image's root assembles (peer-mapped buffer, one xGMI link per rank; the root rotates
@@ -55,9 +57,13 @@ def parse():
                     "image's small serial kernels overlap the other's wide ones (per-kernel event times then include the sharing)")
     ap.add_argument("--fixed-root", action="store_true", help="N > 1, put gather: rank 0 assembles every file (default: the assembling rank "
                     "rotates from image to image, so that the strips of consecutive images arrive over different GPUs' links)")
-    ap.add_argument("--tables-ahead", action="store_true", help="one GPU, experiment: three handles, image i's tables built on a side stream "
-                    "(mij_encode_tables) while image i-1's entropy coder runs. Measured 1.246 against 1.265 ms per image: the cross-queue "
-                    "dependency costs ~25 us of the ~45 it hides, and the wide kernels slow down a little beside it -- not the default")
+    ap.add_argument("--no-tables-ahead", dest="tables_ahead", action="store_false",
+                    help="one GPU: two handles and every kernel of an image in issue order on one stream (rounds 1-2's loop). Default since "
+                         "round 3: three handles, image i's table build (one workgroup, 40 us during which the other 255 CUs would idle) on a "
+                         "side stream (mij_encode_tables) under image i-1's entropy coder; every other kernel of every image still runs alone "
+                         "on the main stream, so the per-kernel event times behind `roofline` are undisturbed. Measured 1.205 against 1.227 ms")
+    ap.add_argument("--tables-ahead", dest="tables_ahead", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(tables_ahead=True)
     ap.add_argument("--also-two-streams", action="store_true", help="after the timed region, time the same loop on two streams as well and "
                     "report it as `two_streams` (off by default: a profiler run of the default command must see the headline loop only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -360,7 +366,7 @@ def worker(args):
     want_put = world > 1 and args.gather == "put" and os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" and not args.progressive
     # One GPU, optimised tables: three handles, so that image i's transform can be issued while i-1 waits for its entropy coder and
     # i-2 for collection (tables-ahead loop below).
-    tables_ahead = world == 1 and optimize and not args.progressive and args.tables_ahead and not args.two_streams
+    tables_ahead = world == 1 and optimize and not args.progressive and args.tables_ahead and not args.two_streams and not args.also_two_streams
     n_handles = 1 if args.progressive or (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1") else (sharded.DEPTH if want_put else (3 if tables_ahead else 2))
     encs = [sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
                                            restart_interval=args.restart_interval, progressive=args.progressive) for _ in range(n_handles)]
@@ -380,7 +386,8 @@ def worker(args):
     cache, stage_acc = {"device": dev}, {}
 
     # Images in flight. Every step still produces a complete file inside the timed region.
-    #  * One GPU: two handles alternate; what disappears is the GPU idling during the host's round trip for the result.
+    #  * One GPU: three handles (two with --no-tables-ahead, fixed tables or two streams) take turns; what disappears is the GPU idling
+    #    during the host's round trip for the result and, by default, during the one-workgroup table build (tables-ahead loop below).
     #  * N GPUs, "put" (sharded.DevicePipeline): four images in flight, sizes all-gathered device to device, strips written
     #    straight into the peer-mapped buffer of the image's root (which rotates over the ranks); no host wait inside a step. If the buffers cannot be mapped, or with
     #    --gather sendrecv: sharded.StripPipeline (two in flight, sizes via the host, RCCL send/recv).

@@ -120,6 +120,26 @@ def test_reconstruction_from_coefficients_equals_decoding_the_file(mij, oracle, 
     assert np.array_equal(d_R.cpu().numpy(), res)
 
 
+def test_reconstruction_from_coefficients_refuses_what_it_cannot_do(mij, oracle):
+    """mij_encode_residual_device: before any transform there are no coefficients; a strip handle cannot upsample across its
+    borders; a pitch shorter than a row is an argument error. Errors, never a crash."""
+    import torch
+    W, H = 256, 128
+    d = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    with mij.Encoder(W, H, 90, True, 1) as enc:
+        with pytest.raises(mij.MiJpegError, match="coefficients"):
+            enc.residual_device(None, W * 3, d.data_ptr(), "bgr")
+        enc.encode_device(d.data_ptr(), W * 3, "bgr")
+        with pytest.raises(mij.MiJpegError, match="pitch"):
+            enc.residual_device(None, W * 3 - 1, d.data_ptr(), "bgr")
+        enc.residual_device(None, W * 3, d.data_ptr(), "bgr")            # and now it works
+        torch.cuda.synchronize()
+    with mij.Encoder(W, H, 90, True, 1, restart_interval=16, strip_mcu_row0=0, strip_mcu_rows=8) as strip:
+        strip.encode_device(d.data_ptr(), W * 3, "bgr")
+        with pytest.raises(mij.MiJpegError, match="whole images"):
+            strip.residual_device(None, W * 3, d.data_ptr(), "bgr")
+
+
 def test_fullsize_decode_and_secondary_compression(mij, oracle):
     """BASELINE config 5: 8320x40000 q95 4:2:2: encode -> decode -> difference map -> re-encode, round trip."""
     import torch

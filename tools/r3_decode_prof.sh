@@ -1,13 +1,14 @@
 #!/bin/bash
 # per-kernel times of the full-size decode for a few settings of the speculative tail / the side stream
 cd /tmp && export TMPDIR=/tmp
-for cfg in "1 0" "1 256" "0 256"; do
+# (the side-stream form measured with this script in round 3 is no longer in the library; what remains are the speculative tail
+#  MIJ_PAR_TAIL and the sparse-pass threshold MIJ_PAR_SPARSE)
+for cfg in "1024 0" "1024 256" "0 256"; do
   set -- $cfg
   out=$GRAFT_REPO_ROOT/gpurun_out/prof_dec_$1_$2; rm -rf $out; mkdir -p $out
-  if [ "$1" = "1" ]; then export MIJ_PAR_SERIAL=1; else unset MIJ_PAR_SERIAL; fi
-  export MIJ_PAR_TAIL=$2
+  export MIJ_PAR_SPARSE=$1 MIJ_PAR_TAIL=$2
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out -o dec --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/decode_fullsize.py > $out/log.txt 2>&1
-  echo "== serial=$1 tail=$2 rc=$?"; python3 - $out <<'PY'
+  echo "== sparse_max=$1 tail=$2 rc=$?"; python3 - $out <<'PY'
 import csv,glob,sys,collections
 f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))

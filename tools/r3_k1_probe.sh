@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: what bounds K1? (a) grid size now that four workgroups are resident per CU, (b) the no-statistics kernel without its
+# round 3: what bounds K1? (a) grid size, (b) the no-statistics kernel without its stores / loads (timing-only variants), (c) rounds 1-2 kernel switches (results: profiles/r03_k1_grid.txt, r03_k1_variants.txt; the ticket / stagger / persistent-K4 builds those files also mention were removed from the library after measuring)
 # stores / loads (timing-only variants), (c) r2's kernel on the same box.
 cd $GRAFT_REPO_ROOT
 for n in 4 5 6 8 12 16; do

@@ -24,6 +24,9 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "nt_loads": {"MIJ_K1_NT_LOADS": 1},
     "k4_nt_loads": {"MIJ_COEF_NT_LOADS": 1},
     "rtz_dot3": {"MIJ_K1_RTZ": 1, "MIJ_K1_DOT3": 1},
+    "sched_ilp": {"_FLAGS": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
+    "sched_mem": {"_FLAGS": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]},
+    # (-amdgpu-sched-strategy=iterative-ilp crashes this hipcc; max-ilp / max-memory-clause: K1 unchanged, K4 4 % slower with scratch)
     "waves2": {"MIJ_K1_WAVES": 2},
     "copies2": {"MIJ_HIST_COPIES": 2},
     "no_atomics": {"MIJ_K1_STATMODE": 1},
@@ -52,8 +55,9 @@ def build_one(name, defs):
         objs = []
         for src in ("mij_kernels.hip", "mij_api.hip", "mij_decode_api.hip"):
             obj = os.path.join(d, src.replace(".hip", ".o"))
+            flags = defs.get("_FLAGS", [])           # a variant may also carry extra compiler flags
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + ([] if os.environ.get("MIJ_VARIANTS_FULL") else ["-DMIJ_FAST_BUILD"]) + [
-                   "-Rpass-analysis=kernel-resource-usage"] + ["-D%s=%s" % kv for kv in defs.items()] + ["-c", os.path.join(CSRC, src), "-o", obj]
+                   "-Rpass-analysis=kernel-resource-usage"] + flags + ["-D%s=%s" % kv for kv in defs.items() if kv[0] != "_FLAGS"] + ["-c", os.path.join(CSRC, src), "-o", obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode:
                 print(r.stderr[-2000:])

@@ -13,7 +13,15 @@ OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {"dec_default": {}, "dec_s256": {"MIJ_PAR_S": 256}, "dec_s384": {"MIJ_PAR_S": 384}, "dec_s512": {"MIJ_PAR_S": 512}, "dec_s640": {"MIJ_PAR_S": 640},
             "dec_s768": {"MIJ_PAR_S": 768}, "dec_s2048": {"MIJ_PAR_S": 2048},
             # write pass with 128 / 256 / 512 lanes per workgroup (the Huffman tables in LDS are per workgroup): tools/decode_hammer.py
-            "dec_wg128": {"MIJ_PAR_WG2": 128}, "dec_wg256": {"MIJ_PAR_WG2": 256}, "dec_wg512": {"MIJ_PAR_WG2": 512}}
+            "dec_wg128": {"MIJ_PAR_WG2": 128}, "dec_wg256": {"MIJ_PAR_WG2": 256}, "dec_wg512": {"MIJ_PAR_WG2": 512},
+            # round 3, the symbol loop: limit compare for long codes; wider look-ahead tables shared by larger workgroups
+            "dec_lim": {"MIJ_PAR_LIMITS": 1},
+            "dec_all256": {"MIJ_PAR_WG01": 256, "MIJ_PAR_WG2": 256},
+            "dec_lb10_128": {"MIJ_PAR_LOOK_BITS": 10, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 128, "MIJ_PAR_WG2": 128},
+            "dec_lb10_256": {"MIJ_PAR_LOOK_BITS": 10, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 256, "MIJ_PAR_WG2": 256},
+            "dec_lb11_256": {"MIJ_PAR_LOOK_BITS": 11, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 256, "MIJ_PAR_WG2": 256},
+            "dec_lb11_512": {"MIJ_PAR_LOOK_BITS": 11, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 512, "MIJ_PAR_WG2": 512},
+            "dec_lb12_512": {"MIJ_PAR_LOOK_BITS": 12, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 512, "MIJ_PAR_WG2": 512}}
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}
 

@@ -16,6 +16,9 @@ VARIANTS = {"dec_default": {}, "dec_s256": {"MIJ_PAR_S": 256}, "dec_s384": {"MIJ
             "dec_wg128": {"MIJ_PAR_WG2": 128}, "dec_wg256": {"MIJ_PAR_WG2": 256}, "dec_wg512": {"MIJ_PAR_WG2": 512},
             # round 3, the symbol loop: limit compare for long codes; wider look-ahead tables shared by larger workgroups
             "dec_lim": {"MIJ_PAR_LIMITS": 1},
+            # EXPERIMENTS with wrong output: what the write pass's global stores cost
+            "dec_nostore": {"MIJ_PAR_NOSTORE": 1}, "dec_nozero": {"MIJ_PAR_NOSTORE": 2},
+            "dec_stg32": {"MIJ_PAR_STG": 32},
             "dec_all256": {"MIJ_PAR_WG01": 256, "MIJ_PAR_WG2": 256},
             "dec_lb10_128": {"MIJ_PAR_LOOK_BITS": 10, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 128, "MIJ_PAR_WG2": 128},
             "dec_lb10_256": {"MIJ_PAR_LOOK_BITS": 10, "MIJ_PAR_LIMITS": 1, "MIJ_PAR_WG01": 256, "MIJ_PAR_WG2": 256},

@@ -1053,8 +1053,11 @@ int mij_encode_residual_device(mij_encoder *e, const void *d_src, size_t pitch, 
   if (s != e->last_stream) HIPCHK(e, hipStreamWaitEvent(s, e->ev_xdone, 0));      // the coefficients were written on another stream
   const size_t ysz = (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8, csz = (size_t)g.mcux * 8 * g.mcuy * 8;
   uint8_t *py = e->d_sec, *pcb = py + ysz, *pcr = pcb + csz;
-  HIPCHK(e, launch_idct_enc(g, e->d_coef, e->d_qt, py, pcb, pcr, s));
-  HIPCHK(e, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, dst_pitch, dst_plane_stride, fmt, s, (const uint8_t *)d_src, pitch, plane_stride));
+  if (idct_color_supported(g, fmt)) HIPCHK(e, launch_idct_color(g, e->d_coef, nullptr, e->d_qt, DcFix(), (uint8_t *)d_dst, dst_pitch, fmt, s, (const uint8_t *)d_src, pitch));
+  else {
+    HIPCHK(e, launch_idct_enc(g, e->d_coef, e->d_qt, py, pcb, pcr, s));
+    HIPCHK(e, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, dst_pitch, dst_plane_stride, fmt, s, (const uint8_t *)d_src, pitch, plane_stride));
+  }
   return MIJ_OK;
 }
 

@@ -480,8 +480,11 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     d_final = d->d_tabs + (ps.scans.size() - 1);
   }
   uint8_t *py = d->d_planes, *pcb = py + ysz, *pcr = pcb + csz;
-  DHIP(d, launch_idct(g, d->d_coef, d_final, py, pcb, pcr, s, dc_fix));
-  DHIP(d, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, pitch, plane_stride, output_format, s));
+  if (idct_color_supported(g, output_format)) DHIP(d, launch_idct_color(g, d->d_coef, d_final, nullptr, dc_fix, (uint8_t *)d_dst, pitch, output_format, s));
+  else {
+    DHIP(d, launch_idct(g, d->d_coef, d_final, py, pcb, pcr, s, dc_fix));
+    DHIP(d, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, pitch, plane_stride, output_format, s));
+  }
   DHIP(d, hipEventRecord(d->ev1, s));
   d->issued = true;
   return MIJ_OK;

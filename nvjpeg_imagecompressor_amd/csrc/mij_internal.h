@@ -197,6 +197,10 @@ hipError_t launch_upsample_color(const Geom &g, const uint8_t *py, const uint8_t
                                  size_t orig_plane_stride = 0);
 // The inverse transform straight from an ENCODER's coefficient buffer (tiled, transposed) and quantisation table.
 hipError_t launch_idct_enc(const Geom &g, const int16_t *coef, const Quant *qt, uint8_t *py, uint8_t *pcb, uint8_t *pcr, hipStream_t s);
+// k_idct + k_upsample_color in one kernel where idct_color_supported() (k_decode.inc: k_idct_color)
+bool idct_color_supported(const Geom &g, int out_fmt);
+hipError_t launch_idct_color(const Geom &g, const int16_t *coef, const DecTables *tab, const Quant *qt, const DcFix &fix, uint8_t *dst, size_t pitch,
+                             int out_fmt, hipStream_t s, const uint8_t *orig = nullptr, size_t orig_pitch = 0);
 hipError_t launch_residual(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int sign, hipStream_t s);
 
 }  // namespace mij

@@ -252,6 +252,43 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_the_two_kernel_inverse_transform_stays_covered():
+    """Samplings without vertical subsampling take the fused inverse transform + colour conversion (k_idct_color) by default;
+    MIJ_FUSED_IDCT=0 keeps k_idct + k_upsample_color8 for them. Both must give Pillow's pixels -- decoding a file, and
+    reconstructing from an encoder's coefficients (D and the difference map R). The switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import io, sys, numpy as np
+from PIL import Image
+sys.path.insert(0, %r)
+import torch
+import nvjpeg_imagecompressor_amd as mij
+from oracle import oracle as O
+dev = torch.device("cuda:0")
+for (W, H) in ((1040, 136), (129, 65), (17, 33), (2064, 24)):
+    img = O.synth_rgb(W, H)
+    for css in (0, 1, 4):                      # 4:4:4, 4:2:2, 4:1:1
+        with mij.Encoder(W, H, 88, True, css) as enc, mij.Decoder() as dec:
+            j = enc.encode_host(img, "rgb")
+            want = np.asarray(Image.open(io.BytesIO(j)).convert("RGB"))
+            assert np.array_equal(dec.decode_host(j, "rgb"), want), ("decode", W, H, css)
+            src = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+            enc.encode_device(src.data_ptr(), W * 3, "rgb")
+            d = torch.empty_like(src); r = torch.empty_like(src)
+            enc.residual_device(None, 0, d.data_ptr(), "rgb", dst_pitch=W * 3)
+            enc.residual_device(src.data_ptr(), W * 3, r.data_ptr(), "rgb", dst_pitch=W * 3)
+            torch.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy(), want), ("D", W, H, css)
+            assert np.array_equal(r.cpu().numpy(), np.clip(img.astype(np.int32) - want + 128, 0, 255).astype(np.uint8)), ("R", W, H, css)
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fused in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MIJ_FUSED_IDCT=fused), timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (fused, r.stderr[-2000:])
+
+
 def test_corrupt_files_are_survivable(mij, oracle):
     """Damaged input must come back as an error or as (wrong) pixels -- never hang or fault: truncated files, a DRI that
     promises more markers than the data holds, bytes flipped in the entropy-coded data, for both entropy routes."""

@@ -16,6 +16,10 @@ VARIANTS = {"dec_default": {}, "dec_s256": {"MIJ_PAR_S": 256}, "dec_s384": {"MIJ
             "dec_wg128": {"MIJ_PAR_WG2": 128}, "dec_wg256": {"MIJ_PAR_WG2": 256}, "dec_wg512": {"MIJ_PAR_WG2": 512},
             # round 3, the symbol loop: limit compare for long codes; wider look-ahead tables shared by larger workgroups
             "dec_lim": {"MIJ_PAR_LIMITS": 1},
+            # wider look-ahead for the speculative / synchronisation passes only (the write pass keeps 9 bits and 64 lanes)
+            "dec01_lb10_128": {"MIJ_PAR_LOOK_BITS": 10, "MIJ_PAR_WG01": 128}, "dec01_lb11_256": {"MIJ_PAR_LOOK_BITS": 11, "MIJ_PAR_WG01": 256},
+            "dec01_lb12_512": {"MIJ_PAR_LOOK_BITS": 12, "MIJ_PAR_WG01": 512}, "dec01_lb11_128": {"MIJ_PAR_LOOK_BITS": 11, "MIJ_PAR_WG01": 128},
+            "dec01_lb10_64": {"MIJ_PAR_LOOK_BITS": 10},
             # EXPERIMENTS with wrong output: what the write pass's global stores cost
             "dec_nostore": {"MIJ_PAR_NOSTORE": 1}, "dec_nozero": {"MIJ_PAR_NOSTORE": 2},
             "dec_stg32": {"MIJ_PAR_STG": 32},

@@ -20,6 +20,9 @@ VARIANTS = {"dec_default": {}, "dec_s256": {"MIJ_PAR_S": 256}, "dec_s384": {"MIJ
             "dec01_lb10_128": {"MIJ_PAR_LOOK_BITS": 10, "MIJ_PAR_WG01": 128}, "dec01_lb11_256": {"MIJ_PAR_LOOK_BITS": 11, "MIJ_PAR_WG01": 256},
             "dec01_lb12_512": {"MIJ_PAR_LOOK_BITS": 12, "MIJ_PAR_WG01": 512}, "dec01_lb11_128": {"MIJ_PAR_LOOK_BITS": 11, "MIJ_PAR_WG01": 128},
             "dec01_lb10_64": {"MIJ_PAR_LOOK_BITS": 10},
+            # the same for the write pass (on top of the 11-bit / 256-lane default of the other two)
+            "dec2_lb10_64": {"MIJ_PAR_LOOK_BITS2": 10}, "dec2_lb10_128": {"MIJ_PAR_LOOK_BITS2": 10, "MIJ_PAR_WG2": 128},
+            "dec2_lb11_256": {"MIJ_PAR_LOOK_BITS2": 11, "MIJ_PAR_WG2": 256}, "dec2_lb9_128": {"MIJ_PAR_WG2": 128},
             # EXPERIMENTS with wrong output: what the write pass's global stores cost
             "dec_nostore": {"MIJ_PAR_NOSTORE": 1}, "dec_nozero": {"MIJ_PAR_NOSTORE": 2},
             "dec_stg32": {"MIJ_PAR_STG": 32},

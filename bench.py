@@ -13,9 +13,15 @@ put -> sendrecv -> serial; the line then carries "gather_fallback": "<reason>". 
 launcher's other ranks leave at once, so both command shapes run the same children with the same safety net
 (MIJ_BENCH_DIRECT=1: be a plain rank of the external launcher instead, no supervisor).
 
-A "step" is one whole encode of the image. On one GPU three handles take turns: image i's transform, the entropy coder of image
-i-1 and the collection of image i-2 overlap on the host side, and image i's table build (one workgroup) runs on a side stream
-under image i-1's entropy coder; every other kernel runs alone on the main stream (--no-tables-ahead: two handles, one stream). At N > 1 the image is cut into restart-interval-aligned strips of MCU
+A "step" is one whole encode of the image. On one GPU (round 4) the timed loop runs the transform of image i on one HIP stream
+and the entropy stage (tables, Huffman coding, size scan, stuffing + compaction) of image i-1 on a second one, three handles taking
+turns, so the issue-bound transform and the latency-bound coder share the machine (--loop overlap, the default; --loop
+tables-ahead / one-stream / two-streams are the earlier rounds' loops). Everything the line says about a SINGLE kernel -- `roofline`,
+`stage_roofline`, `stage_ms` -- comes from a short separate pass right AFTER the timed region in which every kernel of an image runs alone
+on one stream, labelled as such, followed by a stage-A-alone pass (the transform without the fused statistics, the kernel the
+north-star's 70 % is about). The shader clock needs tens of milliseconds of load to settle, more than W = 5 warm-up steps last: behind
+the warm-up steps the same loop runs on, untimed, in rounds of ten steps until two clock readings agree (clock.settle_steps), and
+`clock` records what the clock was right before and right after the timed region and after each pass. At N > 1 the image is cut into restart-interval-aligned strips of MCU
 rows, one per rank (nvjpeg_imagecompressor_amd/sharded.py): transform+statistics locally, ONE all-reduce
 of the 4x257 symbol statistics (RCCL), entropy coding locally, all-gather of strip sizes (device to device), and every
 rank PUTS its strip into the file the image's root assembles (peer-mapped buffer, one xGMI link per rank; the root rotates
@@ -53,19 +59,23 @@ def parse():
     ap.add_argument("--progressive", action="store_true", help="SOF2 output (the reference's nvJPEG setting); 1 GPU only, not the headline config")
     ap.add_argument("--fmt", default="bgr", choices=["bgr", "rgb"])
     ap.add_argument("--restart-interval", type=int, default=-1, help="DRI in MCUs; -1 = the library's automatic choice (the headline config)")
-    ap.add_argument("--two-streams", action="store_true", help="experiment: the two images in flight run on two HIP streams, so one "
-                    "image's small serial kernels overlap the other's wide ones (per-kernel event times then include the sharing)")
+    ap.add_argument("--loop", default=None, choices=["overlap", "tables-ahead", "one-stream", "two-streams"],
+                    help="one GPU, the loop behind `value`. overlap (default): transform of image i on one stream, entropy stage of image i-1 on "
+                         "another, three handles; tables-ahead (round 3): all wide kernels on one stream, the one-workgroup table build on a "
+                         "side stream; one-stream (rounds 1-2): two handles, every kernel in issue order on one stream; two-streams: two "
+                         "handles, each image entirely on its own stream. The per-kernel figures of the line always come from the separate "
+                         "one-stream pass, whatever the loop")
+    ap.add_argument("--two-streams", action="store_true", help=argparse.SUPPRESS)           # = --loop two-streams (round 2-3 spelling)
+    ap.add_argument("--no-tables-ahead", dest="tables_ahead", action="store_false", help=argparse.SUPPRESS)   # = --loop one-stream
+    ap.add_argument("--tables-ahead", dest="tables_ahead", action="store_true", help=argparse.SUPPRESS)       # = --loop tables-ahead
+    ap.set_defaults(tables_ahead=None)
+    ap.add_argument("--settle-rounds", type=int, default=8, help="one GPU: at most this many untimed rounds of ten steps of the timed loop behind the "
+                    "warm-up steps, ended as soon as two successive shader-clock readings agree within 1 %% (0 = none); reported as clock.settle_steps")
+    ap.add_argument("--kernel-pass", type=int, default=10, help="one GPU: images of the separate one-stream pass the per-kernel times come from")
+    ap.add_argument("--stage-a-pass", type=int, default=10, help="one GPU: launches of the transform WITHOUT statistics (stage A alone) timed "
+                    "after the kernel pass (0 = skip)")
     ap.add_argument("--fixed-root", action="store_true", help="N > 1, put gather: rank 0 assembles every file (default: the assembling rank "
                     "rotates from image to image, so that the strips of consecutive images arrive over different GPUs' links)")
-    ap.add_argument("--no-tables-ahead", dest="tables_ahead", action="store_false",
-                    help="one GPU: two handles and every kernel of an image in issue order on one stream (rounds 1-2's loop). Default since "
-                         "round 3: three handles, image i's table build (one workgroup, 40 us during which the other 255 CUs would idle) on a "
-                         "side stream (mij_encode_tables) under image i-1's entropy coder; every other kernel of every image still runs alone "
-                         "on the main stream, so the per-kernel event times behind `roofline` are undisturbed. Measured 1.205 against 1.227 ms")
-    ap.add_argument("--tables-ahead", dest="tables_ahead", action="store_true", help=argparse.SUPPRESS)
-    ap.set_defaults(tables_ahead=True)
-    ap.add_argument("--also-two-streams", action="store_true", help="after the timed region, time the same loop on two streams as well and "
-                    "report it as `two_streams` (off by default: a profiler run of the default command must see the headline loop only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1000, help="rows per CPU-baseline strip (one strip per core)")
@@ -269,6 +279,12 @@ def supervise(args, world, launcher):
                     runs["sendrecv"] = {"failed": reason2}
                 out["gather_runs"] = runs
                 out["gather_runs_note"] = "two complete runs with fresh ranks, one per gather; this line is the faster one's"
+            if not getattr(args, "no_cpu_baseline", True) and "jpeg_crc32" in out and "cpu_baseline" not in out:
+                # libjpeg-turbo on the box's host cores in the same run, at every N: the supervisor holds no GPU and its ranks are gone
+                try:
+                    out.update(cpu_baseline_fields(args, not args.no_optimize, out["config"]["restart_interval"], out["jpeg_crc32"], out["jpeg_bytes"]))
+                except Exception as ex:      # noqa: BLE001 -- the measured line stands without its CPU legs
+                    out["cpu_baseline_error"] = repr(ex)[:300]
             print(json.dumps(out), flush=True)
             return 0
         failures.append("%s: %s" % (mode, reason))
@@ -322,6 +338,240 @@ def _inject(rank, gather, where):
 
 
 def worker(args):
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return worker_one_gpu(args)
+    return worker_ranks(args)
+
+
+def _one_gpu_loop(args, optimize):
+    """Which loop produces `value` on one GPU (see --loop)."""
+    loop = args.loop
+    if loop is None:
+        if args.two_streams:
+            loop = "two-streams"
+        elif args.tables_ahead is False:
+            loop = "one-stream"
+        elif args.tables_ahead is True:
+            loop = "tables-ahead"
+        else:
+            loop = "overlap"
+    if args.progressive:
+        return "progressive"          # one handle, the ten scans on the library's own four streams
+    if loop == "tables-ahead" and not optimize:
+        loop = "one-stream"           # fixed tables: nothing to build ahead
+    return loop
+
+
+def _clock(torch, mij, where):
+    """Effective shader clock right now (mij_clock_probe_device: ~0.9 ms of a fixed vector-ALU loop on every SIMD)."""
+    c = mij.clock_probe_device(1024, torch.cuda.current_stream().cuda_stream)
+    return {"when": where, "valu_MHz": round(c["valu_mhz"], 1), "counter_MHz": round(c["counter_mhz"], 1)}
+
+
+def _smi_clocks():
+    """What the SMI tool says about clocks and the power cap, if an ordinary user may ask (informational; never fails the bench)."""
+    import re
+    import subprocess
+    out = {}
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showmaxpower", "--showpower", "--showperflevel"], capture_output=True, text=True, timeout=20)
+        for key, pat in (("sclk_MHz", r"GPU\[0\].*sclk clock level.*\((\d+)Mhz\)"), ("mclk_MHz", r"GPU\[0\].*mclk clock level.*\((\d+)Mhz\)"),
+                         ("power_cap_W", r"GPU\[0\].*Max Graphics Package Power \(W\):\s*([\d.]+)"),
+                         ("socket_power_W", r"GPU\[0\].*Current Socket Graphics Package Power \(W\):\s*([\d.]+)"),
+                         ("perf_level", r"GPU\[0\].*Performance Level:\s*(\w+)")):
+            m = re.search(pat, r.stdout)
+            if m:
+                out[key] = m.group(1) if key == "perf_level" else float(m.group(1))
+    except Exception as ex:      # noqa: BLE001
+        out["error"] = repr(ex)[:120]
+    out["note"] = "rocm-smi, read while the GPU is idle between the passes (sclk then shows a sleep state): informational"
+    return out
+
+
+def worker_one_gpu(args):
+    import torch
+    import nvjpeg_imagecompressor_amd as mij
+    from nvjpeg_imagecompressor_amd import sharded
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    optimize = not args.no_optimize
+    W, H = args.width, args.height
+    loop = _one_gpu_loop(args, optimize)
+    n_handles = {"overlap": 3, "tables-ahead": 3, "one-stream": 2, "two-streams": 2, "progressive": 1}[loop]
+    encs = [sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, 0, 1, 0, args.fmt,
+                                           restart_interval=args.restart_interval, progressive=args.progressive) for _ in range(n_handles)]
+    geo = encs[0].geometry
+    rows = geo["strip_rows"]
+    main = torch.cuda.current_stream().cuda_stream
+    d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
+    mij.synth_image_device(d_img.data_ptr(), W, 0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=main)
+    strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=False) for e in encs]
+    torch.cuda.synchronize()
+    clocks = [_clock(torch, mij, "start (device idle before)")]
+    copy_gbs, copy_lib_gbs = hbm_copy_ceiling(torch, mij, dev)
+
+    # ---- the timed loop ---------------------------------------------------------------------------------------------------
+    side = torch.cuda.Stream() if loop in ("overlap", "tables-ahead", "two-streams") else None
+    side_s = side.cuda_stream if side is not None else main
+    state = {"i": 0, "q": [], "last": None}            # q: issued and not yet collected, oldest first; last: the newest collected file
+
+    def issue(st):
+        e = st.enc
+        if loop == "overlap":            # K1 on the main stream; K3 K4 K5 K6 on the side stream, behind the transform by event
+            e.transform(st.d_img.data_ptr(), st.pitch, st.fmt, 0, main)
+            if optimize:
+                e.tables(side_s)
+            e.entropy(side_s)
+        elif loop == "tables-ahead":     # all wide kernels on the main stream; the one-workgroup table build on the side stream
+            e.transform(st.d_img.data_ptr(), st.pitch, st.fmt, 0, main)
+            e.tables(side_s)
+            if state["q"]:
+                state["q"][-1].enc.entropy(main)          # the previous image's entropy stage, behind this image's transform
+        elif loop == "two-streams":
+            st.issue_whole(main if state["i"] & 1 else side_s)
+        else:                            # one-stream, progressive
+            st.issue_whole(main)
+
+    def drain():
+        if loop == "tables-ahead" and state["q"]:
+            state["q"][-1].enc.entropy(main)
+        while state["q"]:
+            state["last"] = state["q"].pop(0).finish_whole()
+        return state["last"]
+
+    def step():
+        st = strips[state["i"] % n_handles]
+        issue(st)
+        state["i"] += 1
+        state["q"].append(st)
+        if len(state["q"]) >= n_handles:          # the handle the next step needs: collect its image while the others run
+            state["last"] = state["q"].pop(0).finish_whole()
+        return state["last"]
+
+    def fence():
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    fence()
+    # The shader clock needs tens of milliseconds of THIS load to settle (from idle the first ~20 images of the loop run 5-25 % slower
+    # while it ramps, tools/r4_clock_transient.py): W warm-up steps of 1.1 ms each do not get there. So, still untimed, the same loop
+    # runs on in rounds of ten steps until two successive clock readings agree within 1 % (at most `--settle-rounds` rounds).
+    settle_steps = 0
+    clocks.append(_clock(torch, mij, "after the warm-up steps"))
+    for r in range(max(0, args.settle_rounds)):
+        for _ in range(10):
+            step()
+        drain()
+        fence()
+        settle_steps += 10
+        clocks.append(_clock(torch, mij, "after settle round %d" % (r + 1)))
+        a, b = clocks[-2]["counter_MHz"] or clocks[-2]["valu_MHz"], clocks[-1]["counter_MHz"] or clocks[-1]["valu_MHz"]
+        if abs(a - b) <= 0.01 * b:
+            break
+    clocks[-1]["when"] += " = right before the timed region"
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    jpeg_t = drain()
+    fence()
+    dt = time.perf_counter() - t0
+    clocks.append(_clock(torch, mij, "right after the timed region"))
+    ms_per_step = dt / args.steps * 1e3
+    value = (W * H / 1e6) / (ms_per_step / 1e3)
+    jpeg_keep = jpeg_t.clone()
+
+    # ---- per-kernel pass: every kernel of an image alone on ONE stream, events around each (the library's own, mij_stage_times) ----
+    stage_acc = {}
+    kp = max(1, args.kernel_pass)
+    encs[0].enable_timing(True)
+    jpeg_kp = None
+    for i in range(kp + 2):
+        strips[0].issue_whole(main)
+        jpeg_kp = strips[0].finish_whole()
+        if i >= 2:
+            for k, v in encs[0].stage_times().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+    encs[0].enable_timing(False)
+    stages = {k: v / kp for k, v in stage_acc.items()}
+    jpeg_kp = jpeg_kp.clone()            # fingerprinted in report(): a 204-MB copy to the host here would let the clock fall back
+    clocks.append(_clock(torch, mij, "after the per-kernel pass"))
+
+    # ---- stage A alone: the transform WITHOUT the fused statistics (what a fixed-table encoder runs), same pixels ----
+    stage_a = None
+    if args.stage_a_pass > 0 and not args.progressive:
+        ea = encs[0] if not optimize else sharded.make_hip_strip_encoder(torch, W, H, args.quality, False, args.css, 0, 1, 0, args.fmt,
+                                                                         restart_interval=args.restart_interval)
+        sa = strips[0] if not optimize else sharded.HipStripEncoder(torch, ea, d_img, args.fmt, shared_statistics=False)
+        ea.enable_timing(True)
+        acc, each = 0.0, []
+        for i in range(args.stage_a_pass + 2):
+            sa.issue_whole(main)
+            sa.finish_whole()
+            if i >= 2:
+                t = ea.stage_times()["transform"]
+                acc += t
+                each.append(t)
+        ea.enable_timing(False)
+        ms_a = acc / args.stage_a_pass
+        bytes_a = algorithmic_bytes_per_pixel(args.css, 0.0)["transform"] * rows * W
+        stage_a = {"kernel": "k_transform without statistics (fixed-table encoder, same pixels)", "launches": args.stage_a_pass,
+                   "avg_launch_ms": round(ms_a, 4), "min_launch_ms": round(min(each), 4), "achieved": round(bytes_a / (ms_a * 1e-3) / 1e9, 1),
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_a / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes_per_launch": int(bytes_a),
+                   "note": "hipEvents around each launch on its stream, kernel alone on the device, after the timed region"}
+        clocks.append(_clock(torch, mij, "after the stage-A pass"))
+        if optimize:
+            ea.close()
+            del sa, ea
+
+    # ---- one image alone: issue -> complete file (what the reference's one event pair around nvjpegEncodeImage times, .cu:279-291) ----
+    lat = []
+    for _ in range(5):
+        fence()
+        t1 = time.perf_counter()
+        issue(strips[0])
+        state["i"] += 1
+        state["q"].append(strips[0])
+        drain()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    single_ms = sorted(lat)[len(lat) // 2]
+    smi = _smi_clocks()
+    for e in encs[1:]:
+        e.close()
+
+    ctx = dict(world=1, rank=0, W=W, H=H, optimize=optimize, geo=geo, rows=rows, value=value, ms_per_step=ms_per_step, jpeg_t=jpeg_keep,
+               stages=stages, n_handles=n_handles, gather_mode=None, dpipe=None, copy_gbs=copy_gbs, copy_lib_gbs=copy_lib_gbs, d_img=d_img,
+               root_files=None, want_put=False, one_device=False, rccl_ranks=None, single_ms=None, put_rate=None,
+               streams=(1 if loop in ("one-stream", "progressive") else 2),
+               pipeline={"overlap": "transform of image i on one stream, entropy stage (tables, coder, scan, compaction) of image i-1 on a second one; three handles",
+                         "tables-ahead": "image i's table build (one workgroup) on a side stream under image i-1's entropy coder; all other kernels of all images on one stream",
+                         "two-streams": "two handles, each image entirely on its own stream", "one-stream": "two handles, every kernel in issue order on one stream",
+                         "progressive": "one handle; the ten scans on the library's four internal streams"}[loop])
+    extra = {"loop": loop,
+             "per_kernel_pass": {"images": kp, "streams": 1, "file_identical_to_timed_loop": None,
+                                 "note": "`roofline`, `stage_roofline` and `stage_ms` come from this pass: one image at a time on ONE stream, every kernel "
+                                         "alone on the device, right AFTER the timed region; the timed loop overlaps kernels of different images, so a "
+                                         "kernel's duration inside it includes the sharing"},
+             "single_image_ms": round(single_ms, 4),
+             "single_image_note": "one image alone, issue to complete file with nothing else in flight (host clock, median of 5): the figure "
+                                  "comparable with the reference's one event pair around nvjpegEncodeImage (ImageCompressorImpl.cu:279-291); its "
+                                  "device-event counterpart is stage_ms.total",
+             "clock": {"probes": clocks, "settle_steps": settle_steps, "smi": smi,
+                       "note": "valu_MHz = issue rate of a fixed 4-cycle vector-ALU loop on every SIMD (8 waves per SIMD, ~0.9 ms, launch overhead "
+                               "included, so a lower bound); counter_MHz = shader-clock counter over constant-rate counter inside the same launch"}}
+    if stage_a is not None:
+        extra["stage_A_alone"] = stage_a
+    extra["_kp_file"] = jpeg_kp
+    rc = report(args, torch, mij, ctx, extra)
+    encs[0].close()
+    return rc
+
+
+def worker_ranks(args):
     import datetime
     import torch
     import torch.distributed as dist
@@ -343,31 +593,26 @@ def worker(args):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     rccl_ranks = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # A collective that does not complete within the bound ends the rank (RCCL's watchdog), the supervisor sees it die
-        # and starts fresh processes with the next gather: nothing waits for ever.
-        coll_timeout = datetime.timedelta(seconds=float(os.environ.get("MIJ_BENCH_COLL_TIMEOUT_S", "120")))
-        if one_device:
-            dist.init_process_group("gloo", timeout=coll_timeout)
-        else:
-            dist.init_process_group("nccl", device_id=dev, timeout=coll_timeout)
-            ones = torch.ones(1, dtype=torch.int32, device=dev)
-            dist.all_reduce(ones)                    # how many ranks RCCL really joined
-            rccl_ranks = int(ones.item())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # A collective that does not complete within the bound ends the rank (RCCL's watchdog), the supervisor sees it die
+    # and starts fresh processes with the next gather: nothing waits for ever.
+    coll_timeout = datetime.timedelta(seconds=float(os.environ.get("MIJ_BENCH_COLL_TIMEOUT_S", "120")))
+    if one_device:
+        dist.init_process_group("gloo", timeout=coll_timeout)
+    else:
+        dist.init_process_group("nccl", device_id=dev, timeout=coll_timeout)
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)                    # how many ranks RCCL really joined
+        rccl_ranks = int(ones.item())
     _progress(rank, "process group up")
     _inject(rank, args.gather, "init")
     optimize = not args.no_optimize
     W, H = args.width, args.height
 
     # ---- strip partition (pure arithmetic, no communication) + this rank's pixels --------------------------------
-    # One handle per image in flight: 2 on one GPU (the host collects image i-1 while image i runs), DEPTH on N GPUs.
     whole_geo, r0_, r1_ = sharded.strip_rows(W, H, args.quality, optimize, args.css, rank, world, args.restart_interval)
-    want_put = world > 1 and args.gather == "put" and os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" and not args.progressive
-    # One GPU, optimised tables: three handles, so that image i's transform can be issued while i-1 waits for its entropy coder and
-    # i-2 for collection (tables-ahead loop below).
-    tables_ahead = world == 1 and optimize and not args.progressive and args.tables_ahead and not args.two_streams and not args.also_two_streams
-    n_handles = 1 if args.progressive or (world > 1 and os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1") else (sharded.DEPTH if want_put else (3 if tables_ahead else 2))
+    want_put = args.gather == "put" and os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" and not args.progressive
+    n_handles = 1 if args.progressive or os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1" else (sharded.DEPTH if want_put else 2)
     encs = [sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
                                            restart_interval=args.restart_interval, progressive=args.progressive) for _ in range(n_handles)]
     enc = encs[0]                     # None: this rank owns no strip (more ranks than restart-aligned strips)
@@ -378,7 +623,7 @@ def worker(args):
     if enc is not None:
         d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
         mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
-        strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=world > 1) for e in encs]
+        strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=True) for e in encs]
     strip = strips[0]
     torch.cuda.synchronize()
 
@@ -386,38 +631,28 @@ def worker(args):
     cache, stage_acc = {"device": dev}, {}
 
     # Images in flight. Every step still produces a complete file inside the timed region.
-    #  * One GPU: three handles (two with --no-tables-ahead, fixed tables or two streams) take turns; what disappears is the GPU idling
-    #    during the host's round trip for the result and, by default, during the one-workgroup table build (tables-ahead loop below).
-    #  * N GPUs, "put" (sharded.DevicePipeline): four images in flight, sizes all-gathered device to device, strips written
-    #    straight into the peer-mapped buffer of the image's root (which rotates over the ranks); no host wait inside a step. If the buffers cannot be mapped, or with
-    #    --gather sendrecv: sharded.StripPipeline (two in flight, sizes via the host, RCCL send/recv).
+    #  * "put" (sharded.DevicePipeline): four images in flight, sizes all-gathered device to device, strips written straight into the
+    #    peer-mapped buffer of the image's root (which rotates over the ranks); no host wait inside a step. If the buffers cannot be
+    #    mapped, or with --gather sendrecv: sharded.StripPipeline (two in flight, sizes via the host, RCCL send/recv).
     #    MIJ_BENCH_NO_PIPELINE=1: one image at a time (sharded.encode_step).
     pipelined = n_handles > 1
-    gather_mode, pipe, dpipe = None, None, None
-    if world > 1:
-        gather_mode = "sendrecv"
-        if want_put:
-            targets = sharded.open_file_targets(torch, dist, strips if enc is not None else None, rank, world, dev_index, whole_geo)
-            if targets is not None:
-                dpipe = sharded.DevicePipeline(torch, dist, strips if enc is not None else None, targets, optimize, device=dev,
-                                               rotate=not args.fixed_root, comms=args.comms)
-                gather_mode = "put"
-        if dpipe is None and pipelined:
-            unit = sharded.rows_per_restart_unit(whole_geo["mcus_per_row"], whole_geo["restart_interval"])
-            if (whole_geo["mcu_rows"] + unit - 1) // unit < world:      # the same arithmetic on every rank: all of them stop
-                raise SystemExit("the send/recv pipeline needs a strip on every rank (more ranks than restart-aligned strips)")
-            pipe = sharded.StripPipeline(torch, dist, strips[:2], optimize)
-    _progress(rank, "pipeline ready (%s)" % (gather_mode or "one GPU"))
+    gather_mode, pipe, dpipe = "sendrecv", None, None
+    if want_put:
+        targets = sharded.open_file_targets(torch, dist, strips if enc is not None else None, rank, world, dev_index, whole_geo)
+        if targets is not None:
+            dpipe = sharded.DevicePipeline(torch, dist, strips if enc is not None else None, targets, optimize, device=dev,
+                                           rotate=not args.fixed_root, comms=args.comms)
+            gather_mode = "put"
+    if dpipe is None and pipelined:
+        unit = sharded.rows_per_restart_unit(whole_geo["mcus_per_row"], whole_geo["restart_interval"])
+        if (whole_geo["mcu_rows"] + unit - 1) // unit < world:      # the same arithmetic on every rank: all of them stop
+            raise SystemExit("the send/recv pipeline needs a strip on every rank (more ranks than restart-aligned strips)")
+        pipe = sharded.StripPipeline(torch, dist, strips[:2], optimize)
+    _progress(rank, "pipeline ready (%s)" % gather_mode)
     _inject(rank, args.gather, "pipeline")
     timed_handles = [] if dpipe is not None else [e for e in encs if e is not None]
     for e in timed_handles:
         e.enable_timing(True)
-    state = {"i": 0, "pending": None, "transformed": None}
-    side = torch.cuda.Stream() if tables_ahead else None
-    streams = [torch.cuda.current_stream().cuda_stream] * 2
-    if pipelined and world == 1 and args.two_streams:
-        second = torch.cuda.Stream()
-        streams = [streams[0], second.cuda_stream]
 
     def record_times(e):
         for k, v in e.stage_times().items():
@@ -432,28 +667,7 @@ def worker(args):
             if record and prev is not None:
                 record_times(prev[0].enc)
             return out
-        if tables_ahead:                          # drain: collect the coded image, then code and collect the transformed one
-            out = None
-            if state["pending"] is not None:
-                out = state["pending"].finish_whole()
-                if record:
-                    record_times(state["pending"].enc)
-                state["pending"] = None
-            if state["transformed"] is not None:
-                last, state["transformed"] = state["transformed"], None
-                last.enc.entropy(streams[0])
-                out = last.finish_whole()
-                if record:
-                    record_times(last.enc)
-            return out
-        s_prev = state["pending"]
-        state["pending"] = None
-        if s_prev is None:
-            return None
-        out = s_prev.finish_whole()
-        if record:
-            record_times(s_prev.enc)
-        return out
+        return None
 
     def step(record):
         if not pipelined:
@@ -464,55 +678,28 @@ def worker(args):
         if dpipe is not None:
             dpipe.step()                          # enqueue only: no host wait, no result yet
             return None
-        if pipe is not None:
-            prev = pipe.pending
-            out = pipe.step()                     # issues this image, then completes the previous one
-            if record and prev is not None:
-                record_times(prev[0].enc)
-            return out
-        if tables_ahead:
-            # Software pipeline over three handles, all wide kernels on ONE stream (so their event times are their own):
-            #   main: K1(i)                    K4 K5 K6(i-1)                 K1(i+1) ...
-            #   side:        K3(i) -- one workgroup, ~45 us -- runs under K4(i-1) instead of leaving the device idle
-            # and the host collects image i-2 while the device is busy with the two behind it.
-            cur = strips[state["i"] % 3]
-            state["i"] += 1
-            cur.enc.transform(cur.d_img.data_ptr(), cur.pitch, cur.fmt, 0, streams[0])
-            cur.enc.tables(side.cuda_stream)
-            prev = state["transformed"]
-            if prev is not None:
-                prev.enc.entropy(streams[0])
-            out = None
-            if state["pending"] is not None:
-                out = state["pending"].finish_whole()
-                if record:
-                    record_times(state["pending"].enc)
-            state["pending"], state["transformed"] = prev, cur
-            return out
-        cur = strips[state["i"] & 1]
-        cur.issue_whole(streams[state["i"] & 1])
-        state["i"] += 1
-        out = collect(record)          # the previous image, while this one runs
-        state["pending"] = cur
+        prev = pipe.pending
+        out = pipe.step()                         # issues this image, then completes the previous one
+        if record and prev is not None:
+            record_times(prev[0].enc)
         return out
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(False)
         _heartbeat(rank, "warm-up step %d" % i)
     collect(False)
-    # Put pipeline: one image per ROOT collected and fingerprinted before anything is timed (the timed loop only ever looks at
-    # its last file). Every root must have assembled the same bytes; rank 0 compares them with the timed region's file below.
-    root_files = None
-    if dpipe is not None:
+
+    def verify_roots(what):
+        """One image per ROOT collected and fingerprinted (the timed loop only ever looks at its last file). Every root must have
+        assembled the same bytes; rank 0 compares them with the timed region's file."""
         mine = []
         for i in range(dpipe.nroots):
-            _heartbeat(rank, "verifying root %d" % i)
+            _heartbeat(rank, "%s: verifying root %d" % (what, i))
             dpipe.step()
             o = dpipe.collect()
             if o is not None:
@@ -520,9 +707,12 @@ def worker(args):
                 mine.append("%08x:%d" % (zlib.crc32(b), len(b)))
         every = [None] * world
         dist.all_gather_object(every, mine)
-        root_files = [c for lst in every for c in lst]
-        if len(set(root_files)) != 1 or len(root_files) != dpipe.nroots:
-            raise SystemExit("put pipeline: the %d roots assembled different files: %s" % (dpipe.nroots, root_files))
+        files = [c for lst in every for c in lst]
+        if len(set(files)) != 1 or len(files) != dpipe.nroots:
+            raise SystemExit("put pipeline (%s): the %d roots assembled different files: %s" % (what, dpipe.nroots, files))
+        return files
+
+    root_files = verify_roots("before the timed region") if dpipe is not None else None
     fence()
     _progress(rank, "warm-up done")
     t0 = time.perf_counter()
@@ -534,73 +724,74 @@ def worker(args):
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     value = (W * H / 1e6) / (ms_per_step / 1e3)
     steps_timed = args.steps
     _progress(rank, "timed region done")
-    jpeg_keep = jpeg_t.clone() if (world > 1 and jpeg_t is not None) else jpeg_t     # later images reuse the buffers
+    jpeg_keep = jpeg_t.clone() if jpeg_t is not None else jpeg_t     # later images reuse the buffers
     single_ms, put_rate = None, None
-    if world > 1:
-        if dpipe is not None and dpipe.last_root != 0:      # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
-            # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
-            lr = dpipe.last_root
-            nb = torch.zeros(1, dtype=torch.int64, device=dev)
-            if rank == lr:
-                nb[0] = jpeg_keep.numel()
-            dist.broadcast(nb, src=lr)
-            if rank == lr:
-                dist.send(jpeg_keep, dst=0)
-            elif rank == 0:
-                jpeg_keep = torch.empty(int(nb.item()), dtype=torch.uint8, device=dev)
-                dist.recv(jpeg_keep, src=lr)
-        # ONE image alone through the same path, start to complete file (what a caller with a single image waits for; the
-        # `value` above is the rate with several images in flight). Max over ranks, median of five.
-        lat = []
-        for i in range(5):
-            _heartbeat(rank, "latency %d" % i)
-            fence()
-            t1 = time.perf_counter()
-            if dpipe is not None:
-                dpipe.step()
-                dpipe.flush()
-            elif pipe is not None:
-                pipe.step()
-                pipe.flush()
-            else:
-                sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t1)
-        tl = torch.tensor(lat, dtype=torch.float64, device=dev)
-        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-        single_ms = sorted(tl.tolist())[len(lat) // 2] * 1e3
+    if dpipe is not None and dpipe.last_root != 0:
+        # the last file was assembled on another rank: bring it to rank 0 for the checks below (untimed)
+        lr = dpipe.last_root
+        nb = torch.zeros(1, dtype=torch.int64, device=dev)
+        if rank == lr:
+            nb[0] = jpeg_keep.numel()
+        dist.broadcast(nb, src=lr)
+        if rank == lr:
+            dist.send(jpeg_keep, dst=0)
+        elif rank == 0:
+            jpeg_keep = torch.empty(int(nb.item()), dtype=torch.uint8, device=dev)
+            dist.recv(jpeg_keep, src=lr)
+    if dpipe is not None:
+        # the same per-root check on images assembled AFTER the timed region (buffers, mappings and streams as the loop left them)
+        root_files = root_files + verify_roots("after the timed region")
+    # ONE image alone through the same path, start to complete file (what a caller with a single image waits for; the
+    # `value` above is the rate with several images in flight). Max over ranks, median of five.
+    lat = []
+    for i in range(5):
+        _heartbeat(rank, "latency %d" % i)
+        fence()
+        t1 = time.perf_counter()
         if dpipe is not None:
-            # what a link gives k_put: strip bytes / event time around the put, one image alone (no other traffic), a few roots
-            samples = []
-            for e in encs:
-                if e is not None:
-                    e.enable_timing(True)
-            for _ in range(max(1, min(3, dpipe.nroots))):
-                fence()
-                k = dpipe.step()
-                root = dpipe.roots[k]
-                dpipe.flush()
-                if enc is not None and rank != root:
-                    _, p_ms = encs[k].place_times()
-                    samples.append((rank, root, int(dpipe.sizes[k][rank].item()), p_ms))
-            for e in encs:
-                if e is not None:
-                    e.enable_timing(False)
-            every = [None] * world
-            dist.all_gather_object(every, samples)
-            rates = sorted(b / (ms * 1e-3) / 1e9 for lst in every for (_, _, b, ms) in lst if ms > 0 and b > 0)
-            if rates:
-                put_rate = {"min": round(rates[0], 2), "median": round(rates[len(rates) // 2], 2), "max": round(rates[-1], 2), "samples": len(rates),
-                            "strip_MB": round(max(b for lst in every for (_, _, b, _) in lst) / 1e6, 2),
-                            "note": "k_put alone on its stream, hipEvents around it; one image in flight"}
-        _progress(rank, "latency and put rate done")
+            dpipe.step()
+            dpipe.flush()
+        elif pipe is not None:
+            pipe.step()
+            pipe.flush()
+        else:
+            sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    tl = torch.tensor(lat, dtype=torch.float64, device=dev)
+    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+    single_ms = sorted(tl.tolist())[len(lat) // 2] * 1e3
+    if dpipe is not None:
+        # what a link gives k_put: strip bytes / event time around the put, one image alone (no other traffic), a few roots
+        samples = []
+        for e in encs:
+            if e is not None:
+                e.enable_timing(True)
+        for _ in range(max(1, min(3, dpipe.nroots))):
+            fence()
+            k = dpipe.step()
+            root = dpipe.roots[k]
+            dpipe.flush()
+            if enc is not None and rank != root:
+                _, p_ms = encs[k].place_times()
+                samples.append((rank, root, int(dpipe.sizes[k][rank].item()), p_ms))
+        for e in encs:
+            if e is not None:
+                e.enable_timing(False)
+        every = [None] * world
+        dist.all_gather_object(every, samples)
+        rates = sorted(b / (ms * 1e-3) / 1e9 for lst in every for (_, _, b, ms) in lst if ms > 0 and b > 0)
+        if rates:
+            put_rate = {"min": round(rates[0], 2), "median": round(rates[len(rates) // 2], 2), "max": round(rates[-1], 2), "samples": len(rates),
+                        "strip_MB": round(max(b for lst in every for (_, _, b, _) in lst) / 1e6, 2),
+                        "note": "k_put alone on its stream, hipEvents around it; one image in flight"}
+    _progress(rank, "latency and put rate done")
     if dpipe is not None:
         # The put pipeline records no per-stage events (nothing in it touches the host). For the stage table, code one more
         # image the host-synchronised way, outside the timed region, with events on.
@@ -615,134 +806,150 @@ def worker(args):
             print("stage-time pass failed: %r" % (ex,), file=sys.stderr)
             stage_acc.clear()
         fence()
-    jpeg_t = jpeg_keep
-
-    # Informational second figure (--also-two-streams; one GPU, headline path only): the same loop with the two images in flight on TWO HIP
-    # streams, where one image's narrow kernels (DC statistics, tables, scan) and the wide kernels' tails overlap the other
-    # image's wide kernels. It is NOT `value`: per-kernel event times then include the sharing, so the stage times and the
-    # roofline above come from the one-stream run.
-    two_streams = None
-    if pipelined and world == 1 and args.also_two_streams and not args.two_streams:
-        jpeg_keep = jpeg_t.clone()
-        second = torch.cuda.Stream()
-        streams[1] = second.cuda_stream
-        for _ in range(2):
-            step(False)
-        collect(False)
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(False)
-        collect(False)
-        fence()
-        ms2 = (time.perf_counter() - t1) / args.steps * 1e3
-        streams[1] = streams[0]
-        two_streams = {"ms_per_step": round(ms2, 4), "value": round((W * H / 1e6) / (ms2 / 1e3), 1), "unit": "Mpixels/s", "streams": 2,
-                       "note": "same loop, the two images in flight on two HIP streams; informational, not `value`"}
-        jpeg_t = jpeg_keep
-
-    # ---- rank 0: verify, report ----------------------------------------------------------------------------------
+    rc = 0
     if rank == 0:
-        jpeg = jpeg_t.cpu().numpy().tobytes()
-        fingerprint = "%08x:%d" % (zlib.crc32(jpeg), len(jpeg))
-        if root_files is not None and set(root_files) != {fingerprint}:
-            raise SystemExit("put pipeline: the files collected from the roots (%s) differ from the timed region's file (%s)" % (root_files, fingerprint))
-        ratio = len(jpeg) / (3.0 * W * H)
-        stages = {k: v / steps_timed for k, v in stage_acc.items()}
-        strip_px = rows * W
-        bpp = algorithmic_bytes_per_pixel(args.css, ratio)
-        kname = {"transform": "k_transform", "entropy": "k_encode", "compact": "k_compact"}
-        stage_roof = {}
-        for k in kname:
-            if args.progressive and k != "transform":
-                continue          # progressive: the ten scans are reported together under stage_ms["tables"]
-            if stages.get(k, 0) > 0:
-                gbs = bpp[k] * strip_px / (stages[k] * 1e-3) / 1e9
-                stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                 "frac_of_copy_ceiling": round(gbs / copy_gbs, 4) if copy_gbs else None,
-                                 "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
-        if stage_roof and not args.progressive:
-            dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
-            traffic, traffic_src = measured_traffic(kname[dom], args, optimize and not args.progressive, world, mij.library_source_hash())
-            roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": stage_roof[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
-                        "note": "avg launch duration from hipEvents on the kernels' stream over the timed steps"}
-            if _VALU.get(kname[dom]):
-                # What actually bounds this path: vector instruction issue. At the 3-5 waves per SIMD these
-                # kernels run at, a wave64 vector instruction occupies its SIMD for ~4 cycles; PMC count (same passes, same hash).
-                n = _VALU[kname[dom]]
-                sm = 1024 * 2.4e9 / 4.0         # wave-instructions per second: 1,024 SIMDs at 2.4 GHz, 4 cycles each
-                roofline["valu_issue"] = {"wave_instructions": n[kname[dom]], "floor_ms_at_4_cycles": round(n[kname[dom]] / sm * 1e3, 4),
-                                          "frac_of_launch": round(n[kname[dom]] / sm * 1e3 / stage_roof[dom]["ms"], 3),
-                                          "all_kernels_floor_ms": round(sum(n.values()) / sm * 1e3, 4),
-                                          "note": "SQ_INSTS_VALU per launch; the step is bound by vector issue, not by HBM"}
-            if dom == "transform" and optimize:
-                # K1 also takes the AC statistics (SURVEY 8d stage B, a separate 2(1+f) B/px read in an unfused design);
-                # against stage A + B's algorithmic bytes, as SURVEY 8d prescribes for a fused kernel:
-                fused = (bpp["transform"] + bpp_stage_b(args.css)) * strip_px / (stage_roof[dom]["ms"] * 1e-3) / 1e9
-                roofline["frac_vs_stage_A_plus_B_bytes"] = round(fused / HBM_PEAK_GBS, 4)
-        else:   # --progressive: twenty lane-per-interval passes sequenced by the host; not a roofline-shaped workload
-            roofline = {"bound": "hbm", "kernel": "k_prog_encode", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-        out = {
-            "metric": "Mpixels/s encode (+PSNR, ratio) 8320x40000 q95 4:2:2 @1/2/4/8 GPU",
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d RGB8 (%s interleaved, device resident) -> %s JFIF, q%d, 4:%s:%s, %s Huffman, "
-                                   "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
-                                                    args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
-                       "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
-                       "images_in_flight": n_handles, "gather": gather_mode if os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" or world == 1 else "serial",
-                       "comms": (dpipe.comms if dpipe is not None else None),
-                       "root": (None if dpipe is None else ("rank 0" if args.fixed_root else "rotating over the ranks, image by image")),
-                       "streams": n_handles if dpipe is not None else (2 if (pipelined and world == 1 and args.two_streams) else 1),
-                       "pipeline": ("tables-ahead: image i's table build (one workgroup) on a side stream under image i-1's entropy coder; "
-                                    "all other kernels of all images on one stream") if tables_ahead else None},
-            "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
-            "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None,
-            "hbm_copy_ceiling_note": "own 16-B/lane copy kernel (k_copy16), read + write bytes; torch copy_ on the same box: %s GB/s" % (round(copy_lib_gbs, 1) if copy_lib_gbs else None), "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-        }
-        out["library_source_hash"] = mij.library_source_hash()
-        golden = golden_fingerprint(args, optimize, geo["restart_interval"])
-        if golden is not None:          # the committed fingerprint of this exact configuration (tests/golden/, computed on the CPU)
-            out["golden_match"] = golden == (out["jpeg_crc32"], out["jpeg_bytes"])
-        if world > 1:
-            out["rccl_ranks"] = rccl_ranks
-            out["collective_backend"] = "gloo (one-device rehearsal)" if one_device else "nccl (RCCL)"
-            out["single_image_latency_ms"] = round(single_ms, 4) if single_ms is not None else None
-            out["single_image_latency_note"] = "one image alone, issue to complete file on its root, max over ranks, median of 5"
-            out["put_GB/s"] = put_rate
-            if root_files is not None:
-                out["files_verified"] = {"roots": len(root_files), "identical_to_timed_file": True}
-            if want_put and dpipe is None:
-                out["gather_note"] = "the output buffers could not be peer-mapped (hipIpc*): every rank took send/recv"
-        if two_streams:
-            out["two_streams"] = two_streams
-        if not args.no_psnr:
-            out["psnr_db"], out["psnr_note"] = _psnr_check(jpeg, W, H, args.fmt, d_img if world == 1 else None)
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baselines(args, optimize, geo["restart_interval"])
-            # The baseline north_star names is libjpeg-turbo on the box's host cores; kind "port" = the stock CPU library whose
-            # arithmetic oracle/ restates byte for byte (there is no oracle/_ref: the reference's nvJPEG cannot be built here).
-            if "turbo" in cb:
-                out["cpu_baseline"] = dict(cb["turbo"], kind="port", impl="libjpeg-turbo 3.1.4.1 via Pillow (SIMD), all host cores")
-                out["cpu_baseline_1core"] = dict(cb["turbo_1core"], impl="libjpeg-turbo 3.1.4.1 via Pillow, one core (the library's native mode)")
-            elif "ijg" in cb:
-                out["cpu_baseline"] = dict(cb["ijg"], kind="port", impl="IJG libjpeg 9d C API (non-SIMD; Pillow's libjpeg-turbo cannot write 4:4:0 / 4:1:1), all host cores")
-                if "ijg_1core" in cb:
-                    out["cpu_baseline_1core"] = dict(cb["ijg_1core"], impl="IJG libjpeg 9d C API (non-SIMD), one core")
-            else:
-                out["cpu_baseline"] = dict(cb["port"], kind="port", impl="oracle/jpeg_oracle.c")
-            out["cpu_oracle_port"] = dict(cb["port"], impl="oracle/jpeg_oracle.c (the checker, OpenMP-free, one strip per core)")
-        print(json.dumps(out), flush=True)
+        ctx = dict(world=world, rank=rank, W=W, H=H, optimize=optimize, geo=geo, rows=rows, value=value, ms_per_step=ms_per_step, jpeg_t=jpeg_keep,
+                   stages={k: v / steps_timed for k, v in stage_acc.items()}, n_handles=n_handles, gather_mode=gather_mode, dpipe=dpipe,
+                   copy_gbs=copy_gbs, copy_lib_gbs=copy_lib_gbs, d_img=None, root_files=root_files, want_put=want_put, one_device=one_device,
+                   rccl_ranks=rccl_ranks, single_ms=single_ms, put_rate=put_rate, streams=n_handles if dpipe is not None else 1, pipeline=None)
+        rc = report(args, torch, mij, ctx, {})
     for e in encs:
         if e is not None:
             e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return rc
+
+
+def report(args, torch, mij, c, extra):
+    """Rank 0: verify the file, build and print the JSON line."""
+    world, W, H, optimize, geo, rows = c["world"], c["W"], c["H"], c["optimize"], c["geo"], c["rows"]
+    dpipe, root_files, stages, copy_gbs, copy_lib_gbs = c["dpipe"], c["root_files"], c["stages"], c["copy_gbs"], c["copy_lib_gbs"]
+    jpeg = c["jpeg_t"].cpu().numpy().tobytes()
+    fingerprint = "%08x:%d" % (zlib.crc32(jpeg), len(jpeg))
+    if root_files is not None and set(root_files) != {fingerprint}:
+        raise SystemExit("put pipeline: the files collected from the roots (%s) differ from the timed region's file (%s)" % (root_files, fingerprint))
+    kp_file = extra.pop("_kp_file", None)
+    if kp_file is not None:
+        same = kp_file.cpu().numpy().tobytes() == jpeg
+        extra["per_kernel_pass"]["file_identical_to_timed_loop"] = same
+        if not same:
+            raise SystemExit("the one-stream pass and the timed loop produced different files")
+    ratio = len(jpeg) / (3.0 * W * H)
+    strip_px = rows * W
+    bpp = algorithmic_bytes_per_pixel(args.css, ratio)
+    kname = {"transform": "k_transform", "entropy": "k_encode", "compact": "k_compact"}
+    stage_roof = {}
+    for k in kname:
+        if args.progressive and k != "transform":
+            continue          # progressive: the ten scans are reported together under stage_ms["tables"]
+        if stages.get(k, 0) > 0:
+            gbs = bpp[k] * strip_px / (stages[k] * 1e-3) / 1e9
+            stage_roof[k] = {"kernel": kname[k], "ms": round(stages[k], 4), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "frac_of_copy_ceiling": round(gbs / copy_gbs, 4) if copy_gbs else None,
+                             "algorithmic_bytes_per_launch": int(bpp[k] * strip_px)}
+    lib_hash = mij.library_source_hash()
+    clock_mhz = None
+    probes = extra.get("clock", {}).get("probes") or []
+    around = [p["counter_MHz"] or p["valu_MHz"] for p in probes if "timed region" in p["when"]]
+    if around:
+        clock_mhz = sum(around) / len(around)
+    if stage_roof and not args.progressive:
+        dom = max(stage_roof, key=lambda k: stage_roof[k]["ms"])
+        traffic, traffic_src = measured_traffic(kname[dom], args, optimize and not args.progressive, world, lib_hash)
+        roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": stage_roof[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": stage_roof[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": stage_roof[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": stage_roof[dom]["ms"],
+                    "note": ("avg launch duration from hipEvents around the kernel on its stream, %s"
+                             % ("in the separate one-stream pass after the timed region (per_kernel_pass)" if world == 1 else "over the timed steps"))}
+        if _VALU.get(kname[dom]):
+            # What actually bounds this path (DESIGN.md section 4): vector instruction issue. At the 3-5 waves per SIMD these
+            # kernels run at, a wave64 vector instruction occupies its SIMD for ~4 cycles; PMC count (same passes, same hash).
+            n = _VALU[kname[dom]]
+            mhz = clock_mhz or 2400.0
+            sm = 1024 * mhz * 1e6 / 4.0         # wave-instructions per second: 1,024 SIMDs, 4 cycles each
+            roofline["valu_issue"] = {"wave_instructions": n[kname[dom]], "clock_MHz": round(mhz, 1),
+                                      "clock_source": "measured around the timed region (clock.probes)" if clock_mhz else "assumed",
+                                      "floor_ms": round(n[kname[dom]] / sm * 1e3, 4),
+                                      "frac_of_launch": round(n[kname[dom]] / sm * 1e3 / stage_roof[dom]["ms"], 3),
+                                      "all_kernels_floor_ms": round(sum(n.values()) / sm * 1e3, 4),
+                                      "note": "SQ_INSTS_VALU per launch x 4 cycles / (1,024 SIMDs x clock): the step is bound by vector issue, not by HBM"}
+        if dom == "transform" and optimize:
+            # K1 also takes the AC statistics (SURVEY 8d stage B, a separate 2(1+f) B/px read in an unfused design);
+            # against stage A + B's algorithmic bytes, as SURVEY 8d prescribes for a fused kernel:
+            fused = (bpp["transform"] + bpp_stage_b(args.css)) * strip_px / (stage_roof[dom]["ms"] * 1e-3) / 1e9
+            roofline["frac_vs_stage_A_plus_B_bytes"] = round(fused / HBM_PEAK_GBS, 4)
+        sa = extra.pop("stage_A_alone", None)
+        if sa is not None:
+            t2, src2 = measured_traffic("k_transform_nostats", args, True, world, lib_hash)
+            sa["traffic"], sa["traffic_source"] = t2, src2
+            sa["frac_of_copy_ceiling"] = round(sa["achieved"] / copy_gbs, 4) if copy_gbs else None
+            roofline["stage_A_alone"] = sa
+    else:   # --progressive: twenty lane-per-interval passes sequenced by the host; not a roofline-shaped workload
+        roofline = {"bound": "hbm", "kernel": "k_prog_encode", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        extra.pop("stage_A_alone", None)
+    out = {
+        "metric": "Mpixels/s encode (+PSNR, ratio) 8320x40000 q95 4:2:2 @1/2/4/8 GPU",
+        "value": round(c["value"], 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(c["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%dx%d RGB8 (%s interleaved, device resident) -> %s JFIF, q%d, 4:%s:%s, %s Huffman, "
+                               "DRI=%d MCUs" % (W, H, args.fmt.upper(), "progressive (SOF2)" if args.progressive else "baseline", args.quality,
+                                                args.css[1], args.css[2], "optimised" if optimize else "fixed", geo["restart_interval"]),
+                   "parallelism": "strips%d" % world, "restart_interval": geo["restart_interval"],
+                   "images_in_flight": c["n_handles"], "gather": c["gather_mode"] if os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" or world == 1 else "serial",
+                   "comms": (dpipe.comms if dpipe is not None else None),
+                   "root": (None if dpipe is None else ("rank 0" if args.fixed_root else "rotating over the ranks, image by image")),
+                   "streams": c["streams"], "pipeline": c["pipeline"]},
+        "jpeg_bytes": len(jpeg), "ratio": round(ratio, 5), "jpeg_crc32": "%08x" % zlib.crc32(jpeg),
+        "roofline": roofline, "hbm_copy_ceiling_GB/s": round(copy_gbs, 1) if copy_gbs else None,
+        "hbm_copy_ceiling_note": "own 16-B/lane copy kernel (k_copy16), read + write bytes; torch copy_ on the same box: %s GB/s" % (round(copy_lib_gbs, 1) if copy_lib_gbs else None), "stage_roofline": stage_roof, "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+    }
+    out.update(extra)
+    out["library_source_hash"] = lib_hash
+    golden = golden_fingerprint(args, optimize, geo["restart_interval"])
+    if golden is not None:          # the committed fingerprint of this exact configuration (tests/golden/, computed on the CPU)
+        out["golden_match"] = golden == (out["jpeg_crc32"], out["jpeg_bytes"])
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        out["rccl_ranks"] = c["rccl_ranks"]
+        out["collective_backend"] = "gloo (one-device rehearsal)" if c["one_device"] else "nccl (RCCL)"
+        out["single_image_latency_ms"] = round(c["single_ms"], 4) if c["single_ms"] is not None else None
+        out["single_image_latency_note"] = "one image alone, issue to complete file on its root, max over ranks, median of 5"
+        out["put_GB/s"] = c["put_rate"]
+        if root_files is not None:
+            out["files_verified"] = {"roots": dpipe.nroots, "images": len(root_files), "identical_to_timed_file": True,
+                                     "when": "one image per root before the timed region and one per root after it"}
+        if c["want_put"] and dpipe is None:
+            out["gather_note"] = "the output buffers could not be peer-mapped (hipIpc*): every rank took send/recv"
+    if not args.no_psnr:
+        out["psnr_db"], out["psnr_note"] = _psnr_check(jpeg, W, H, args.fmt, c["d_img"] if world == 1 else None)
+    if world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_fields(args, optimize, geo["restart_interval"], out["jpeg_crc32"], out["jpeg_bytes"]))
+    print(json.dumps(out), flush=True)
     return 0
+
+
+def cpu_baseline_fields(args, optimize, restart_interval, jpeg_crc32, jpeg_bytes):
+    """The CPU legs of the line (run by rank 0 on one GPU, by the supervisor -- which holds no GPU -- at N > 1)."""
+    cb = cpu_baselines(args, optimize, restart_interval)
+    out = {}
+    # The baseline north_star names is libjpeg-turbo on the box's host cores; kind "port" = the stock CPU library whose
+    # arithmetic oracle/ restates byte for byte (there is no oracle/_ref: the reference's nvJPEG cannot be built here).
+    if "turbo" in cb:
+        out["cpu_baseline"] = dict(cb["turbo"], kind="port", impl="libjpeg-turbo 3.1.4.1 via Pillow (SIMD), all host cores")
+        one = dict(cb["turbo_1core"], impl="libjpeg-turbo 3.1.4.1 via Pillow, one core (the library's native mode)")
+        out["cpu_baseline_1core"] = one
+        if one.get("crc32") is not None and one.get("whole_image"):
+            # libjpeg-turbo wrote the WHOLE image on the host in this same run: its file against the GPU's, byte for byte by fingerprint
+            out["turbo_file_identical"] = (one["crc32"] == jpeg_crc32 and one["bytes"] == jpeg_bytes)
+    elif "ijg" in cb:
+        out["cpu_baseline"] = dict(cb["ijg"], kind="port", impl="IJG libjpeg 9d C API (non-SIMD; Pillow's libjpeg-turbo cannot write 4:4:0 / 4:1:1), all host cores")
+        if "ijg_1core" in cb:
+            out["cpu_baseline_1core"] = dict(cb["ijg_1core"], impl="IJG libjpeg 9d C API (non-SIMD), one core")
+    else:
+        out["cpu_baseline"] = dict(cb["port"], kind="port", impl="oracle/jpeg_oracle.c")
+    out["cpu_oracle_port"] = dict(cb["port"], impl="oracle/jpeg_oracle.c (the checker, OpenMP-free, one strip per core)")
+    return out
 
 
 def golden_fingerprint(args, optimize, restart_interval):

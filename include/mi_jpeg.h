@@ -275,6 +275,12 @@ MIJ_API int mij_secondary_decode_host(mij_decoder *dec, const uint8_t *primary, 
 /* Bench utility: the streaming-copy yardstick (16 B per lane, 4 loads in flight): read + write `bytes` each; all three
  * arguments 16-byte aligned. */
 MIJ_API int mij_copy_bench_device(void *d_dst, const void *d_src, size_t bytes, void *stream);
+/* Bench utility: the shader clock the SIMDs actually run at (the encode kernels are bound by vector instruction issue, so a
+ * throughput figure is only comparable between boxes together with it). One launch of a fixed vector-ALU loop at 8 waves per
+ * SIMD: *valu_clock_mhz = issued 4-cycle instructions per SIMD x 4 / launch duration; *counter_clock_mhz (may be NULL) = the
+ * ratio of the shader-clock counter to the constant-rate counter inside that launch x hipDeviceAttributeWallClockRate (0 if
+ * that rate is unknown); *launch_ms (may be NULL) = the launch duration. iters = 1024 runs ~0.9 ms at 2.4 GHz. Synchronous. */
+MIJ_API int mij_clock_probe_device(int iters, void *stream, double *valu_clock_mhz, double *counter_clock_mhz, double *launch_ms);
 MIJ_API int mij_synth_image_device(void *d_dst, int width, int y0, int rows, size_t pitch, int bgr, void *stream);
 
 #ifdef __cplusplus

@@ -27,6 +27,7 @@ EXPORTS = (
     "mij_secondary_encode_host", "mij_secondary_decode_host", "mij_decode_last_ms", "mij_decoder_device",
     "mij_geometry_query", "mij_encode_entropy_sizes", "mij_encode_place", "mij_sharded_result", "mij_encoder_reserve_output",
     "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close", "mij_place_times", "mij_encode_residual_device",
+    "mij_clock_probe_device",
 )
 
 
@@ -128,6 +129,8 @@ def load():
     L.mij_debug_tables.argtypes = [vp, vp]
     L.mij_copy_bench_device.argtypes = [vp, vp, sz, vp]
     L.mij_synth_image_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, sz, C.c_int, vp]
+    dp = C.POINTER(C.c_double)
+    L.mij_clock_probe_device.argtypes = [C.c_int, vp, dp, dp, dp]
     L.mij_decoder_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.mij_decoder_destroy.argtypes = [vp]
     L.mij_decoder_destroy.restype = None

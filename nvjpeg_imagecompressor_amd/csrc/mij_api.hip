@@ -664,6 +664,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_entropy called before mij_encode_transform");
   HIPCHK(e, hipSetDevice(e->p.device));
   hipStream_t s = (hipStream_t)stream;
+  if (s != e->last_stream) HIPCHK(e, hipStreamWaitEvent(s, e->ev_xdone, 0));     // entropy stage on another stream than the transform
   e->last_stream = s;
   const Geom &g = e->g;
   if (e->p.progressive) return encode_progressive(e, s);
@@ -1133,6 +1134,46 @@ int mij_copy_bench_device(void *d_dst, const void *d_src, size_t bytes, void *st
   if (!d_dst || !d_src || (bytes & 15) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) return MIJ_ERR_INVALID_ARG;
   hipError_t he = launch_copy16(d_dst, d_src, bytes, (hipStream_t)stream);
   if (he != hipSuccess) return fail(nullptr, MIJ_ERR_HIP, "k_copy16 launch", he);
+  return MIJ_OK;
+}
+
+int mij_clock_probe_device(int iters, void *stream, double *valu_clock_mhz, double *counter_clock_mhz, double *launch_ms) {
+  if (iters <= 0 || iters > (1 << 20) || !valu_clock_mhz) return MIJ_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int wgs = clock_probe_workgroups();
+  unsigned long long *d_out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<unsigned long long> h((size_t)wgs * 2 + 2);
+  hipError_t he = hipMalloc((void **)&d_out, h.size() * sizeof(unsigned long long));
+  if (he != hipSuccess) return fail(nullptr, MIJ_ERR_ALLOC, "clock probe buffer", he);
+  float ms = 0.f;
+  int dev = 0, wall_khz = 0;
+  he = hipEventCreate(&e0);
+  if (he == hipSuccess) he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = launch_clock_probe(d_out, (uint32_t *)(d_out + (size_t)wgs * 2), wgs, 16, s);      // warm-up: code object, clocks
+  if (he == hipSuccess) he = hipEventRecord(e0, s);
+  if (he == hipSuccess) he = launch_clock_probe(d_out, (uint32_t *)(d_out + (size_t)wgs * 2), wgs, iters, s);
+  if (he == hipSuccess) he = hipEventRecord(e1, s);
+  if (he == hipSuccess) he = hipEventSynchronize(e1);
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  if (he == hipSuccess) he = hipMemcpy(h.data(), d_out, (size_t)wgs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (he == hipSuccess) he = hipGetDevice(&dev);
+  if (he == hipSuccess && hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) wall_khz = 0;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_out);
+  if (he != hipSuccess) return fail(nullptr, MIJ_ERR_HIP, "clock probe", he);
+  // 8 waves per SIMD, each issuing iters x 64 four-cycle instructions: cycles a SIMD spent = 8 x iters x 64 x 4
+  *valu_clock_mhz = ms > 0.f ? 8.0 * iters * 64.0 * 4.0 / (ms * 1e-3) / 1e6 : 0.0;
+  if (counter_clock_mhz) {
+    // median over the workgroups of (shader-clock counter ticks) / (constant-rate counter ticks) x the constant rate
+    std::vector<double> r;
+    for (int i = 0; i < wgs; i++)
+      if (h[2 * i + 1]) r.push_back((double)h[2 * i] / (double)h[2 * i + 1]);
+    std::sort(r.begin(), r.end());
+    *counter_clock_mhz = (r.empty() || wall_khz <= 0) ? 0.0 : r[r.size() / 2] * wall_khz / 1e3;
+  }
+  if (launch_ms) *launch_ms = ms;
   return MIJ_OK;
 }
 

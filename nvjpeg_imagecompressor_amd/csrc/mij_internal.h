@@ -131,6 +131,8 @@ hipError_t launch_compact(const Geom &g, const uint8_t *scratch, size_t slot_byt
                           int root_world = 0);     // root_sizes: the strip goes sum(root_sizes[0 .. root_rank)) bytes into out_scan
 hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t launch_synth(uint8_t *dst, int W, int y0, int rows, size_t pitch, int bgr, hipStream_t s);
+int clock_probe_workgroups();
+hipError_t launch_clock_probe(unsigned long long *out, uint32_t *sink, int workgroups, int iters, hipStream_t s);
 
 // ---- decode path (k_decode.inc) ----
 struct DecTables {                 // built on the host from the file's DHT / DQT / SOF / SOS segments

@@ -315,6 +315,15 @@ def copy_bench_device(d_dst, d_src, nbytes, stream=0):
     _lib.check(L.mij_copy_bench_device(C.c_void_p(d_dst), C.c_void_p(d_src), nbytes, C.c_void_p(stream)), None, "mij_copy_bench_device")
 
 
+def clock_probe_device(iters=1024, stream=0):
+    """Effective shader clock (bench only): {"valu_mhz": from the issue rate of a fixed vector-ALU loop, "counter_mhz": from the
+    shader-clock / constant-rate counter ratio inside the same launch (0.0 if unknown), "launch_ms"}."""
+    L = _lib.load()
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _lib.check(L.mij_clock_probe_device(int(iters), C.c_void_p(stream), C.byref(a), C.byref(b), C.byref(c)), None, "mij_clock_probe_device")
+    return {"valu_mhz": a.value, "counter_mhz": b.value, "launch_ms": c.value}
+
+
 def synth_image_device(d_ptr, width, y0, rows, pitch, bgr=False, stream=0):
     L = _lib.load()
     _lib.check(L.mij_synth_image_device(C.c_void_p(d_ptr), width, y0, rows, pitch, int(bgr), C.c_void_p(stream)),

@@ -205,6 +205,13 @@ def _bench(args, env_extra=None, launcher=False, timeout=900):
 def one_gpu_line():
     d, _ = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-psnr", "--height", "4000"])
     assert d["n_gpus"] == 1 and "launcher" not in d          # N = 1 runs in the process of the command line, as ever
+    # round 4: the loop behind `value` overlaps two images on two streams; per-kernel figures come from a separate one-stream pass
+    assert d["loop"] == "overlap" and d["config"]["streams"] == 2 and d["config"]["images_in_flight"] == 3
+    assert d["per_kernel_pass"]["file_identical_to_timed_loop"] is True and d["per_kernel_pass"]["streams"] == 1
+    assert d["roofline"]["stage_A_alone"]["avg_launch_ms"] > 0 and 0 < d["roofline"]["stage_A_alone"]["frac"] < 1
+    assert d["roofline"]["stage_A_alone"]["avg_launch_ms"] < d["roofline"]["avg_launch_ms"]        # no statistics: the shorter kernel
+    assert len(d["clock"]["probes"]) >= 5 and all(500 < p["valu_MHz"] < 3000 for p in d["clock"]["probes"])
+    assert d["single_image_ms"] > 0
     return d
 
 
@@ -225,7 +232,8 @@ def test_bench_multi_rank_rehearsal(one_gpu_line, gather, comms):
     assert d["library_source_hash"] == one_gpu_line["library_source_hash"]
     assert d["single_image_latency_ms"] > 0 and d["rccl_ranks"] is None and "gloo" in d["collective_backend"]
     if gather == "put":
-        assert d["files_verified"] == {"roots": 3, "identical_to_timed_file": True}
+        # one image per root before the timed region and one per root after it, all equal to the timed region's file
+        assert d["files_verified"]["roots"] == 3 and d["files_verified"]["images"] == 6 and d["files_verified"]["identical_to_timed_file"] is True
         assert d["put_GB/s"]["samples"] >= 2 and d["put_GB/s"]["min"] > 0
 
 

@@ -14,10 +14,14 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 SHORT = {"k_transform": "k_transform", "k_encode": "k_encode", "k_compact": "k_compact", "k_dc_stats": "k_dc_stats",
          "k_build_tables": "k_build_tables", "k_scan_chunks": "k_scan_chunks", "k_scan_totals": "k_scan_totals"}
+
+
+NOSTATS = re.compile(r"k_transform<[^>]*,\s*(false|0)\s*>")
 
 
 def per_kernel(directory, counter):
@@ -26,8 +30,12 @@ def per_kernel(directory, counter):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
+            name = row["Kernel_Name"]
             for key in SHORT:
-                if key in row["Kernel_Name"]:
+                if key in name:
+                    # the transform without the fused statistics (last template argument false): stage A alone, its own entry
+                    if key == "k_transform" and NOSTATS.search(name):
+                        key = "k_transform_nostats"
                     acc[key].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
@@ -61,8 +69,9 @@ def main():
     print(json.dumps({
         "library_source_hash": h_f,
         "workload": "8320x40000 q95 4:2:2 optimised, AUTO restart interval (64 MCUs), 1 GPU (bench.py defaults)",
-        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; "
-                  "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); mean per launch",
+        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1 --kernel-pass 2 --stage-a-pass 2`; "
+                  "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); mean per launch. k_transform_nostats = "
+                  "k_transform<..., false>, the transform without the fused statistics (stage A alone; the bench's stage-A pass launches it)",
         "kernels": kernels}, indent=1))
 
 

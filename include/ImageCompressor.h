@@ -52,9 +52,15 @@ class NVJPEG_COMPRESS_RUNNER_API NvjpegCompressRunner {
   void setRestartInterval(int mcus);       // -1 = automatic
   void setProgressive(bool progressive);   // the reference's encoding (ImageCompressorImpl.cu:28); default false = baseline, the fast path
   // Secondary ("difference map") compression, reference README.md:8: first layer into `primary`, the
-  // JPEG of the difference map is returned; both environments must be built. secondaryDecode puts the pair back together.
+  // JPEG of the difference map is returned. Needs the compress environment only (the first layer's reconstruction comes from
+  // the encoder's own coefficients). secondaryDecode puts the pair back together (decode environment).
+  // The overloads give the second layer its own quality (1..100; 0 = the first layer's), sampling (css as above; -1 = the first
+  // layer's) and a gain (1, 2, 4, 8) applied to the difference before it is coded -- mij_secondary_params in mi_jpeg.h; the
+  // same gain must be passed to secondaryDecode.
   std::vector<unsigned char> secondaryCompress(cv::Mat image, std::vector<unsigned char> &primary, int *run_state);
+  std::vector<unsigned char> secondaryCompress(cv::Mat image, std::vector<unsigned char> &primary, int quality2, int css2, int gain, int *run_state);
   cv::Mat secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int *run_state);
+  cv::Mat secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int gain, int *run_state);
   void setDevice(int device);
   void setVerbose(bool verbose);
   const char *lastError() const;

@@ -165,7 +165,10 @@ MIJ_API int mij_sharded_result(mij_encoder *enc, const uint64_t *d_sizes, int ra
 /* Device times in ms of the last mij_encode_place (mij_encoder_enable_timing before it): [0] stuffing + compaction,
  * [1] the put of the strip into the root's peer-mapped buffer (0 on the root). Strip bytes / [1] = what one xGMI link gave. */
 MIJ_API int mij_place_times(mij_encoder *enc, float ms[2]);
+/* mij_encoder_reserve_output allocates the buffer device-UNCACHED (hipDeviceMallocUncached) when it can: other GPUs write into it
+ * behind this GPU's caches, so no line of it may live in them. mij_output_is_uncached tells (1 / 0). */
 MIJ_API int mij_encoder_reserve_output(mij_encoder *enc, size_t scan_capacity_bytes);
+MIJ_API int mij_output_is_uncached(const mij_encoder *enc);
 MIJ_API int mij_output_buffer(mij_encoder *enc, void **d_buffer, size_t *scan_offset, size_t *scan_capacity);
 #define MIJ_IPC_HANDLE_BYTES 64
 MIJ_API int mij_ipc_export(const void *d_ptr, void *handle64);
@@ -269,6 +272,36 @@ MIJ_API int mij_secondary_encode_host(mij_encoder *enc, mij_decoder *dec, const 
                                       size_t *secondary_bytes);
 MIJ_API int mij_secondary_decode_host(mij_decoder *dec, const uint8_t *primary, size_t primary_bytes, const uint8_t *secondary,
                                       size_t secondary_bytes, uint8_t *dst, size_t pitch, int output_format, int *width, int *height);
+
+/* The second layer with parameters of its own (round 4; reference README.md:8 names the scheme in one sentence and no code, so
+ * the definition is this library's): at the first layer's quality and sampling the difference map is below
+ * the quantiser's step and a second layer adds bytes but hardly any fidelity; coded finer, at full chroma resolution and / or
+ * amplified, it does.
+ *   encode:  J1 = enc(I; encoder's quality, css);  D = dec(J1);  R = clip((I - D) * gain + 128);  J2 = enc(R; quality2, css2)
+ *   decode:  I' = clip(dec(J1) + floor((dec(J2) - 128 + gain / 2) / gain))
+ * Defaults (quality2 = 0, css2 = -1, gain = 0 or 1; or params == NULL) reproduce mij_secondary_encode_host / _decode_host
+ * bit for bit. The second layer is coded by a second encoder handle kept inside `enc` (created on first use, re-created when
+ * quality2 / css2 change, destroyed with `enc`), with the restart interval MIJ_RESTART_AUTO picks for its sampling. Each
+ * layer is an ordinary JFIF file: byte-identical to what a stock encoder makes of I / of R at that layer's settings. The
+ * gain is not stored in either file: the caller passes the same params to the decode side (only `gain` is read there). */
+typedef struct mij_secondary_params {
+  uint32_t struct_size;   /* = sizeof(mij_secondary_params) */
+  int quality2;           /* 1..100; 0 = the first layer's */
+  int css2;               /* MIJ_CSS_*; -1 = the first layer's */
+  int gain;               /* 1, 2, 4 or 8; 0 = 1 */
+} mij_secondary_params;
+#define MIJ_SECONDARY_PARAMS_INIT {(uint32_t)sizeof(mij_secondary_params), 0, -1, 1}
+MIJ_API int mij_secondary_encode_host_ex(mij_encoder *enc, const mij_secondary_params *params, const uint8_t *src, size_t pitch,
+                                         size_t plane_stride, int input_format, uint8_t *primary, size_t *primary_bytes,
+                                         uint8_t *secondary, size_t *secondary_bytes);
+MIJ_API int mij_secondary_decode_host_ex(mij_decoder *dec, const mij_secondary_params *params, const uint8_t *primary, size_t primary_bytes,
+                                         const uint8_t *secondary, size_t secondary_bytes, uint8_t *dst, size_t pitch, int output_format,
+                                         int *width, int *height);
+/* mij_residual_device with the gain above: mode -1: out = clip((a - b) * gain + 128); mode +1: out = clip(a + floor((b - 128 + gain / 2) / gain)). */
+MIJ_API int mij_residual_gain_device(const void *d_a, const void *d_b, void *d_out, size_t n, int mode, int gain, void *stream);
+/* mij_encode_residual_device with the gain above: d_dst <- clip((I - D) * gain + 128) (d_src == NULL: D itself, gain ignored). */
+MIJ_API int mij_encode_residual_gain_device(mij_encoder *enc, const void *d_src, size_t pitch, size_t plane_stride, int input_format,
+                                            void *d_dst, size_t dst_pitch, size_t dst_plane_stride, int gain, void *stream);
 
 /* Bench utility: fill device memory with rows [y0, y0+rows) of the SURVEY.md 8(d) synthetic image
  * (RGB or BGR interleaved). */

@@ -27,7 +27,7 @@ EXPORTS = (
     "mij_secondary_encode_host", "mij_secondary_decode_host", "mij_decode_last_ms", "mij_decoder_device",
     "mij_geometry_query", "mij_encode_entropy_sizes", "mij_encode_place", "mij_sharded_result", "mij_encoder_reserve_output",
     "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close", "mij_place_times", "mij_encode_residual_device",
-    "mij_clock_probe_device",
+    "mij_clock_probe_device", "mij_secondary_encode_host_ex", "mij_secondary_decode_host_ex", "mij_encode_residual_gain_device", "mij_residual_gain_device", "mij_output_is_uncached",
 )
 
 
@@ -42,6 +42,14 @@ class EncoderParams(C.Structure):
             super().__init__(*args, **kw)
         else:
             super().__init__(C.sizeof(EncoderParams), *args, **kw)
+
+
+class SecondaryParams(C.Structure):
+    """mij_secondary_params (include/mi_jpeg.h): the second layer's own quality / sampling and the gain of the difference map."""
+    _fields_ = [("struct_size", C.c_uint32), ("quality2", C.c_int), ("css2", C.c_int), ("gain", C.c_int)]
+
+    def __init__(self, quality2=0, css2=-1, gain=1):
+        super().__init__(C.sizeof(SecondaryParams), int(quality2), int(css2), int(gain))
 
 
 class Geometry(C.Structure):
@@ -120,6 +128,12 @@ def load():
     L.mij_encode_host.argtypes = [vp, vp, sz, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     L.mij_secondary_encode_host.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp, C.POINTER(sz), vp, C.POINTER(sz)]
     L.mij_secondary_decode_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    spp = C.POINTER(SecondaryParams)
+    L.mij_secondary_encode_host_ex.argtypes = [vp, spp, vp, sz, sz, C.c_int, vp, C.POINTER(sz), vp, C.POINTER(sz)]
+    L.mij_secondary_decode_host_ex.argtypes = [vp, spp, vp, sz, vp, sz, vp, sz, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mij_encode_residual_gain_device.argtypes = [vp, vp, sz, sz, C.c_int, vp, sz, sz, C.c_int, vp]
+    L.mij_residual_gain_device.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp]
+    L.mij_output_is_uncached.argtypes = [vp]
     L.mij_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.mij_host_free.argtypes = [vp]
     L.mij_host_free.restype = None

@@ -116,10 +116,17 @@ cv::Mat NvjpegCompressRunner::decode(std::string image_path, int *run_state) {
 }
 
 std::vector<unsigned char> NvjpegCompressRunner::secondaryCompress(cv::Mat image, std::vector<unsigned char> &primary, int *run_state) {
+  return secondaryCompress(image, primary, 0, -1, 1, run_state);
+}
+
+std::vector<unsigned char> NvjpegCompressRunner::secondaryCompress(cv::Mat image, std::vector<unsigned char> &primary, int quality2, int css2, int gain,
+                                                                   int *run_state) {
   std::vector<unsigned char> secondary;
   primary.clear();
-  if (!compressor->enc || !compressor->dec) {
-    std::cerr << "[ERROR] secondaryCompress() needs buildCompressEnv() and buildDecodeEnv()" << std::endl;
+  mij_secondary_params sp = MIJ_SECONDARY_PARAMS_INIT;
+  sp.quality2 = quality2; sp.css2 = css2; sp.gain = gain;
+  if (!compressor->enc) {
+    std::cerr << "[ERROR] secondaryCompress() called before buildCompressEnv() succeeded" << std::endl;
   } else if (image.empty() || image.type() != CV_8UC3 || image.cols != compressor->p.width || image.rows != compressor->p.height) {
     std::cerr << "[ERROR] secondaryCompress(): image must be CV_8UC3 " << compressor->p.width << "x" << compressor->p.height << std::endl;
   } else {
@@ -131,8 +138,8 @@ std::vector<unsigned char> NvjpegCompressRunner::secondaryCompress(cv::Mat image
     for (int attempt = 0; attempt < 4 && rc == MIJ_ERR_OVERFLOW; attempt++) {
       primary.resize(cap1); secondary.resize(cap2);
       size_t n1 = cap1, n2 = cap2;
-      rc = mij_secondary_encode_host(compressor->enc, compressor->dec, image.ptr<unsigned char>(0), image.step, 0, MIJ_INPUT_BGRI, primary.data(),
-                                     &n1, secondary.data(), &n2);
+      rc = mij_secondary_encode_host_ex(compressor->enc, &sp, image.ptr<unsigned char>(0), image.step, 0, MIJ_INPUT_BGRI, primary.data(), &n1,
+                                        secondary.data(), &n2);
       if (rc == MIJ_OK) { primary.resize(n1); secondary.resize(n2); }
       else if (rc == MIJ_ERR_OVERFLOW) { cap1 = std::max(cap1, n1 + n1 / 8 + 4096); cap2 = std::max(cap2, n2 + n2 / 8 + 4096); if (n2 == 0) cap2 = std::max(cap2, cap1); }
     }
@@ -146,14 +153,21 @@ std::vector<unsigned char> NvjpegCompressRunner::secondaryCompress(cv::Mat image
 }
 
 cv::Mat NvjpegCompressRunner::secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int *run_state) {
+  return secondaryDecode(primary, secondary, 1, run_state);
+}
+
+cv::Mat NvjpegCompressRunner::secondaryDecode(const std::vector<unsigned char> &primary, const std::vector<unsigned char> &secondary, int gain,
+                                              int *run_state) {
   cv::Mat result;
   int w = 0, h = 0;
+  mij_secondary_params sp = MIJ_SECONDARY_PARAMS_INIT;
+  sp.gain = gain;
   if (!compressor->dec) {
     std::cerr << "[ERROR] secondaryDecode() called before buildDecodeEnv() succeeded" << std::endl;
   } else if (mij_decode_info(primary.data(), primary.size(), &w, &h, nullptr, nullptr) == MIJ_OK) {
     cv::Mat m(h, w, CV_8UC3);
-    if (mij_secondary_decode_host(compressor->dec, primary.data(), primary.size(), secondary.data(), secondary.size(), m.ptr<unsigned char>(0),
-                                  m.step, MIJ_INPUT_BGRI, &w, &h) == MIJ_OK)
+    if (mij_secondary_decode_host_ex(compressor->dec, &sp, primary.data(), primary.size(), secondary.data(), secondary.size(), m.ptr<unsigned char>(0),
+                                     m.step, MIJ_INPUT_BGRI, &w, &h) == MIJ_OK)
       result = m;
     else
       compressor->err = mij_decoder_last_error(compressor->dec);

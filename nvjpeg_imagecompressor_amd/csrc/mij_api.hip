@@ -57,6 +57,7 @@ struct mij_encoder {
   uint32_t *d_redo = nullptr;               // set by the fused coder when its result is unusable
   bool fuse = false, fused_run = false;
   uint8_t *d_out = nullptr;
+  bool out_uncached = false;   // d_out came from mij_encoder_reserve_output as device-uncached memory (peers write into it)
   size_t capacity = 0;  // scan-data capacity (bytes after HDR_AREA)
   DeviceResult *d_res = nullptr, *h_res = nullptr, *h_res_dev = nullptr;   // h_res_dev: the device's address of the page-locked h_res
   uint8_t *d_src = nullptr;
@@ -65,6 +66,8 @@ struct mij_encoder {
   size_t h_out_cap = 0;
   uint8_t *d_sec = nullptr;   // secondary compression: decoded first layer and residual, same layout as d_src
   size_t d_sec_bytes = 0;
+  mij_encoder *sec_enc = nullptr;   // second layer coded with its own quality / sampling (mij_secondary_encode_host_ex): created on
+  int sec_quality = 0, sec_css = 0; // first use, kept while the parameters stay the same
   hipStream_t s_copy = nullptr, s_work = nullptr;   // mij_encode_host: upload stream / kernel stream
   hipEvent_t ev_chunk[2]{};                          // "chunk i has landed" (ping-pong)
   bool host_streams = false;
@@ -178,6 +181,7 @@ int mij_device_count(void) {
 const char *mij_last_error(const mij_encoder *enc) { return enc ? enc->err.c_str() : g_create_err.c_str(); }
 
 void mij_encoder_destroy(mij_encoder *e) {
+  if (e && e->sec_enc) { mij_encoder_destroy(e->sec_enc); e->sec_enc = nullptr; }
   if (!e) return;
   (void)hipSetDevice(e->p.device);
   if (e->last_stream || e->issued) (void)hipStreamSynchronize(e->last_stream);
@@ -824,13 +828,34 @@ int mij_encoder_reserve_output(mij_encoder *e, size_t scan_capacity) {
   if (scan_capacity <= e->capacity) return MIJ_OK;
   HIPCHK(e, hipSetDevice(e->p.device));
   if (e->issued) HIPCHK(e, hipStreamSynchronize(e->last_stream));
+  // This buffer is what OTHER GPUs write into (k_put through a peer mapping) and what this GPU then reads (mij_retrieve_bitstream,
+  // a decode of the assembled file, a framework's copy kernel). The peers' stores arrive at this device's memory behind its L2s,
+  // which may still hold lines of the same addresses from the handle's earlier images (its own compaction wrote there, its own
+  // k_put read from there). So the buffer is allocated UNCACHED for its owner (hipDeviceMallocUncached: MTYPE UC, no line of it
+  // ever lives in an L2 or L1 of this device) -- what RCCL does with its own peer-written buffers -- and visibility of a peer's
+  // bytes then rests on two things only, both in program order: k_put's system-scope release before it retires, and the
+  // collective the peer enqueues behind it, which this rank's stream waits for. A cached allocation would
+  // lean on the fabric probing this device's L2 on remote writes; no multi-GPU run has ever tested that here.
+  // MIJ_SHARED_OUT=cached keeps plain hipMalloc (A/B experiments on one GPU); if the uncached allocation or its export fails the
+  // plain one is taken as well.
   uint8_t *nb = nullptr;
-  if (hipMalloc(&nb, HDR_AREA + scan_capacity + 64) != hipSuccess) { (void)hipGetLastError(); return fail(e, MIJ_ERR_ALLOC, "cannot reserve the output buffer"); }
+  const size_t bytes = HDR_AREA + scan_capacity + 64;
+  const char *mode = getenv("MIJ_SHARED_OUT");
+  bool uncached = !(mode && strcmp(mode, "cached") == 0);
+  if (uncached) {
+    hipIpcMemHandle_t probe;
+    if (hipExtMallocWithFlags((void **)&nb, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); nb = nullptr; uncached = false; }
+    else if (hipIpcGetMemHandle(&probe, nb) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nb); nb = nullptr; uncached = false; }
+  }
+  if (!nb && hipMalloc(&nb, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(e, MIJ_ERR_ALLOC, "cannot reserve the output buffer"); }
   (void)hipFree(e->d_out);
   e->d_out = nb; e->capacity = scan_capacity;
+  e->out_uncached = uncached;
   e->static_tables_ready = false;      // the header lives in this buffer
   return MIJ_OK;
 }
+
+int mij_output_is_uncached(const mij_encoder *e) { return e && e->out_uncached ? 1 : 0; }
 
 int mij_output_buffer(mij_encoder *e, void **d_buffer, size_t *scan_offset, size_t *scan_capacity) {
   if (!e || !d_buffer) return MIJ_ERR_INVALID_ARG;
@@ -1036,8 +1061,25 @@ static size_t plane_bytes(const Geom &g) {       // Y padded to whole MCUs + Cb 
   return (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8 + 2 * ((size_t)g.mcux * 8 * g.mcuy * 8);
 }
 
+static int gain_to_shift(int gain) { return gain <= 1 ? 0 : gain == 2 ? 1 : gain == 4 ? 2 : gain == 8 ? 3 : -1; }
+
+static int encode_residual(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *d_dst, size_t dst_pitch,
+                           size_t dst_plane_stride, void *stream, int gain_shift);
+
 int mij_encode_residual_device(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *d_dst, size_t dst_pitch,
                                size_t dst_plane_stride, void *stream) {
+  return encode_residual(e, d_src, pitch, plane_stride, fmt, d_dst, dst_pitch, dst_plane_stride, stream, 0);
+}
+
+int mij_encode_residual_gain_device(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *d_dst, size_t dst_pitch,
+                                    size_t dst_plane_stride, int gain, void *stream) {
+  const int sh = gain_to_shift(gain);
+  if (sh < 0) return fail(e, MIJ_ERR_INVALID_ARG, "gain must be 1, 2, 4 or 8");
+  return encode_residual(e, d_src, pitch, plane_stride, fmt, d_dst, dst_pitch, dst_plane_stride, stream, sh);
+}
+
+static int encode_residual(mij_encoder *e, const void *d_src, size_t pitch, size_t plane_stride, int fmt, void *d_dst, size_t dst_pitch,
+                           size_t dst_plane_stride, void *stream, int gain_shift) {
   if (!e || !d_dst) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
   const bool interleaved = fmt == MIJ_INPUT_RGBI || fmt == MIJ_INPUT_BGRI;
   if (!interleaved && fmt != MIJ_INPUT_RGB && fmt != MIJ_INPUT_BGR) return fail(e, MIJ_ERR_INVALID_ARG, "unknown pixel format");
@@ -1054,21 +1096,46 @@ int mij_encode_residual_device(mij_encoder *e, const void *d_src, size_t pitch, 
   if (s != e->last_stream) HIPCHK(e, hipStreamWaitEvent(s, e->ev_xdone, 0));      // the coefficients were written on another stream
   const size_t ysz = (size_t)g.mcux * g.hs * 8 * g.mcuy * g.vs * 8, csz = (size_t)g.mcux * 8 * g.mcuy * 8;
   uint8_t *py = e->d_sec, *pcb = py + ysz, *pcr = pcb + csz;
-  if (idct_color_supported(g, fmt)) HIPCHK(e, launch_idct_color(g, e->d_coef, nullptr, e->d_qt, DcFix(), (uint8_t *)d_dst, dst_pitch, fmt, s, (const uint8_t *)d_src, pitch));
+  Geom gr = g;
+  gr.res_shift = gain_shift;      // only the difference-map stores read it
+  if (idct_color_supported(g, fmt)) HIPCHK(e, launch_idct_color(gr, e->d_coef, nullptr, e->d_qt, DcFix(), (uint8_t *)d_dst, dst_pitch, fmt, s, (const uint8_t *)d_src, pitch));
   else {
     HIPCHK(e, launch_idct_enc(g, e->d_coef, e->d_qt, py, pcb, pcr, s));
-    HIPCHK(e, launch_upsample_color(g, py, pcb, pcr, (uint8_t *)d_dst, dst_pitch, dst_plane_stride, fmt, s, (const uint8_t *)d_src, pitch, plane_stride));
+    HIPCHK(e, launch_upsample_color(gr, py, pcb, pcr, (uint8_t *)d_dst, dst_pitch, dst_plane_stride, fmt, s, (const uint8_t *)d_src, pitch, plane_stride));
   }
   return MIJ_OK;
 }
 
-// Both layers end to end, host memory in and out.
-int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt,
-                              uint8_t *primary, size_t *primary_bytes, uint8_t *secondary, size_t *secondary_bytes) {
+// Both layers end to end, host memory in and out. `sp` (may be null = same settings, gain 1): the second layer's own quality /
+// sampling (coded by a second handle kept inside `e`) and the gain applied to the difference before it is coded.
+int mij_secondary_encode_host_ex(mij_encoder *e, const mij_secondary_params *sp, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt,
+                                 uint8_t *primary, size_t *primary_bytes, uint8_t *secondary, size_t *secondary_bytes) {
   if (!e || !src || !primary || !primary_bytes || !secondary || !secondary_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
   const Geom &g = e->g;
   if (g.mcu_first != 0 || !g.last_strip) return fail(e, MIJ_ERR_INVALID_ARG, "secondary compression works on whole images");
-  if (dec && mij_decoder_device(dec) != e->p.device) return fail(e, MIJ_ERR_INVALID_ARG, "encoder and decoder are on different devices");
+  int q2 = e->p.quality, css2 = e->p.css, sh = 0;
+  if (sp) {
+    if (sp->struct_size != sizeof(mij_secondary_params)) return fail(e, MIJ_ERR_INVALID_ARG, "mij_secondary_params.struct_size matches no known layout");
+    if (sp->quality2 != 0) q2 = sp->quality2;
+    if (sp->css2 >= 0) css2 = sp->css2;
+    sh = gain_to_shift(sp->gain);
+    if (sh < 0) return fail(e, MIJ_ERR_INVALID_ARG, "mij_secondary_params.gain must be 0 (= 1), 1, 2, 4 or 8");
+    if (q2 < 1 || q2 > 100) return fail(e, MIJ_ERR_INVALID_ARG, "mij_secondary_params.quality2 must be 0 (= the first layer's) or 1..100");
+  }
+  mij_encoder *e2 = e;       // the handle that codes the second layer
+  if (q2 != e->p.quality || css2 != e->p.css) {
+    if (e->sec_enc && (e->sec_quality != q2 || e->sec_css != css2)) { mij_encoder_destroy(e->sec_enc); e->sec_enc = nullptr; }
+    if (!e->sec_enc) {
+      mij_encoder_params p2 = e->p;
+      p2.quality = q2; p2.css = css2;
+      if (css2 != e->p.css) p2.restart_interval = MIJ_RESTART_AUTO;      // another MCU size: the interval that suits it
+      p2.strip_mcu_row0 = p2.strip_mcu_rows = 0;
+      int rc2 = mij_encoder_create(&p2, &e->sec_enc);
+      if (rc2) return fail(e, rc2, "cannot create the second layer's encoder (quality2 / css2)");
+      e->sec_quality = q2; e->sec_css = css2;
+    }
+    e2 = e->sec_enc;
+  }
   const uint8_t *j1 = nullptr; size_t n1 = 0;
   int rc = mij_encode_host(e, src, pitch, plane_stride, fmt, &j1, &n1);      // J1; the image stays in e->d_src, its coefficients in e->d_coef
   if (rc) return rc;
@@ -1083,17 +1150,25 @@ int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *s
   if (rc) return rc;
   uint8_t *d_res = e->d_sec + planes;
   hipStream_t s = e->last_stream;
-  // R = clip(I - D + 128) with D = dec(J1) reconstructed from the coefficients J1 was coded from (no decode of the file)
-  rc = mij_encode_residual_device(e, e->d_src, pitch, plane_stride, fmt, d_res, pitch, plane_stride, s);
+  // R = clip(((I - D) << sh) + 128) with D = dec(J1) reconstructed from the coefficients J1 was coded from (no decode of the file)
+  rc = encode_residual(e, e->d_src, pitch, plane_stride, fmt, d_res, pitch, plane_stride, s, sh);
   if (rc) return rc;
-  rc = mij_encode_device(e, d_res, pitch, plane_stride, fmt, s);                        // J2 = enc(R)
-  if (rc) return rc;
+  if (e2 != e) HIPCHK(e, hipStreamSynchronize(s));                                      // the second handle works on its own streams
+  rc = mij_encode_device(e2, d_res, pitch, plane_stride, fmt, e2 == e ? s : nullptr);     // J2 = enc(R)
+  if (rc) return e2 == e ? rc : fail(e, rc, mij_last_error(e2));
   size_t n2 = 0;
-  rc = mij_retrieve_bitstream(e, nullptr, &n2);
-  if (rc) return rc;
+  rc = mij_retrieve_bitstream(e2, nullptr, &n2);
+  if (rc) return e2 == e ? rc : fail(e, rc, mij_last_error(e2));
   *secondary_bytes = n2;
   if (n2 > cap2) return fail(e, MIJ_ERR_OVERFLOW, "secondary buffer too small");
-  return mij_retrieve_bitstream(e, secondary, &n2);
+  rc = mij_retrieve_bitstream(e2, secondary, &n2);
+  return (rc && e2 != e) ? fail(e, rc, mij_last_error(e2)) : rc;
+}
+
+int mij_secondary_encode_host(mij_encoder *e, mij_decoder *dec, const uint8_t *src, size_t pitch, size_t plane_stride, int fmt,
+                              uint8_t *primary, size_t *primary_bytes, uint8_t *secondary, size_t *secondary_bytes) {
+  if (e && dec && mij_decoder_device(dec) != e->p.device) return fail(e, MIJ_ERR_INVALID_ARG, "encoder and decoder are on different devices");
+  return mij_secondary_encode_host_ex(e, nullptr, src, pitch, plane_stride, fmt, primary, primary_bytes, secondary, secondary_bytes);
 }
 
 int mij_stage_times(mij_encoder *e, float ms[MIJ_NUM_STAGE_TIMES]) {

@@ -537,7 +537,19 @@ int mij_decode_host(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, uint
 
 int mij_secondary_decode_host(mij_decoder *d, const uint8_t *primary, size_t primary_bytes, const uint8_t *secondary, size_t secondary_bytes,
                               uint8_t *dst, size_t pitch, int output_format, int *width, int *height) {
+  return mij_secondary_decode_host_ex(d, nullptr, primary, primary_bytes, secondary, secondary_bytes, dst, pitch, output_format, width, height);
+}
+
+int mij_secondary_decode_host_ex(mij_decoder *d, const mij_secondary_params *sp, const uint8_t *primary, size_t primary_bytes,
+                                 const uint8_t *secondary, size_t secondary_bytes, uint8_t *dst, size_t pitch, int output_format, int *width,
+                                 int *height) {
   if (!d || !primary || !secondary || !dst) return dfail(d, MIJ_ERR_INVALID_ARG, "null argument");
+  int gain_shift = 0;
+  if (sp) {       // only the gain matters on the way back: quality and sampling of each layer are in its file
+    if (sp->struct_size != sizeof(mij_secondary_params)) return dfail(d, MIJ_ERR_INVALID_ARG, "mij_secondary_params.struct_size matches no known layout");
+    gain_shift = sp->gain <= 1 ? 0 : sp->gain == 2 ? 1 : sp->gain == 4 ? 2 : sp->gain == 8 ? 3 : -1;
+    if (gain_shift < 0) return dfail(d, MIJ_ERR_INVALID_ARG, "mij_secondary_params.gain must be 0 (= 1), 1, 2, 4 or 8");
+  }
   int w = 0, h = 0, w2 = 0, h2 = 0;
   int rc = mij_decode_info(primary, primary_bytes, &w, &h, nullptr, nullptr);
   if (!rc) rc = mij_decode_info(secondary, secondary_bytes, &w2, &h2, nullptr, nullptr);
@@ -555,7 +567,7 @@ int mij_secondary_decode_host(mij_decoder *d, const uint8_t *primary, size_t pri
   if (!rc) rc = mij_decode_device(d, secondary, secondary_bytes, d->d_out2, row, row * h, output_format, nullptr);
   if (!rc) rc = mij_decode_sync(d, nullptr);
   if (rc) return rc;
-  if (launch_residual(d->d_out, d->d_out2, d->d_out, bytes, +1, nullptr) != hipSuccess) return dfail(d, MIJ_ERR_HIP, "residual kernel");   // I' = clip(D + R' - 128)
+  if (launch_residual(d->d_out, d->d_out2, d->d_out, bytes, +1, nullptr, gain_shift) != hipSuccess) return dfail(d, MIJ_ERR_HIP, "residual kernel");   // I' = clip(D + (R' - 128) / gain)
   DHIP(d, hipMemcpy2D(dst, pitch, d->d_out, row, row, (size_t)h * (interleaved ? 1 : 3), hipMemcpyDeviceToHost));
   if (width) *width = w;
   if (height) *height = h;
@@ -563,8 +575,14 @@ int mij_secondary_decode_host(mij_decoder *d, const uint8_t *primary, size_t pri
 }
 
 int mij_residual_device(const void *d_a, const void *d_b, void *d_out, size_t n, int mode, void *stream) {
+  return mij_residual_gain_device(d_a, d_b, d_out, n, mode, 1, stream);
+}
+
+int mij_residual_gain_device(const void *d_a, const void *d_b, void *d_out, size_t n, int mode, int gain, void *stream) {
   if (!d_a || !d_b || !d_out) return MIJ_ERR_INVALID_ARG;
-  hipError_t he = launch_residual((const uint8_t *)d_a, (const uint8_t *)d_b, (uint8_t *)d_out, n, mode, (hipStream_t)stream);
+  const int sh = gain <= 1 ? 0 : gain == 2 ? 1 : gain == 4 ? 2 : gain == 8 ? 3 : -1;
+  if (sh < 0) return MIJ_ERR_INVALID_ARG;
+  hipError_t he = launch_residual((const uint8_t *)d_a, (const uint8_t *)d_b, (uint8_t *)d_out, n, mode, (hipStream_t)stream, sh);
   return he == hipSuccess ? MIJ_OK : MIJ_ERR_HIP;
 }
 

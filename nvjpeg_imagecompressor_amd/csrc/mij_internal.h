@@ -68,6 +68,7 @@ struct Geom {
   uint32_t mcux_magic;    // floor(2^32 / mcux), saturated
   uint32_t seg0;          // index of the strip's first restart interval = mcu_first / ri
   int nl_sh, mpt_sh;      // log2(nl), log2(MCUs per tile = 256 / nl)
+  int res_shift;          // difference-map kernels only (RES): log2 of the second layer's gain, R = clip(((I - D) << res_shift) + 128)
 };
 inline void geom_finish(Geom &g) {
   const unsigned long long m = 0x100000000ull / (unsigned)g.mcux;
@@ -203,6 +204,6 @@ hipError_t launch_idct_enc(const Geom &g, const int16_t *coef, const Quant *qt, 
 bool idct_color_supported(const Geom &g, int out_fmt);
 hipError_t launch_idct_color(const Geom &g, const int16_t *coef, const DecTables *tab, const Quant *qt, const DcFix &fix, uint8_t *dst, size_t pitch,
                              int out_fmt, hipStream_t s, const uint8_t *orig = nullptr, size_t orig_pitch = 0);
-hipError_t launch_residual(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int sign, hipStream_t s);
+hipError_t launch_residual(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int sign, hipStream_t s, int gain_shift = 0);
 
 }  // namespace mij

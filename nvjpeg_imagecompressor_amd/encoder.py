@@ -93,16 +93,21 @@ class Encoder:
         _lib.check(self._L.mij_place_times(self._h, ms), self._h, "mij_place_times")
         return float(ms[0]), float(ms[1])
 
-    def residual_device(self, d_src, pitch, d_dst, fmt="bgr", plane_stride=0, dst_pitch=None, dst_plane_stride=None, stream=0):
-        """After encode_device / transform of image I on this handle: d_dst <- clip(I - D + 128) with D = what a decoder makes
-        of this handle's file, computed from the coefficients (d_src = I); d_src = 0 / None: d_dst <- D itself."""
-        _lib.check(self._L.mij_encode_residual_device(self._h, C.c_void_p(d_src or 0), pitch, plane_stride, _FMT[fmt], C.c_void_p(d_dst),
-                                                      pitch if dst_pitch is None else dst_pitch,
-                                                      plane_stride if dst_plane_stride is None else dst_plane_stride, C.c_void_p(stream)),
-                   self._h, "mij_encode_residual_device")
+    def residual_device(self, d_src, pitch, d_dst, fmt="bgr", plane_stride=0, dst_pitch=None, dst_plane_stride=None, stream=0, gain=1):
+        """After encode_device / transform of image I on this handle: d_dst <- clip((I - D) * gain + 128) with D = what a decoder
+        makes of this handle's file, computed from the coefficients (d_src = I); d_src = 0 / None: d_dst <- D itself."""
+        _lib.check(self._L.mij_encode_residual_gain_device(self._h, C.c_void_p(d_src or 0), pitch, plane_stride, _FMT[fmt], C.c_void_p(d_dst),
+                                                           pitch if dst_pitch is None else dst_pitch,
+                                                           plane_stride if dst_plane_stride is None else dst_plane_stride, int(gain),
+                                                           C.c_void_p(stream)),
+                   self._h, "mij_encode_residual_gain_device")
 
     def reserve_output(self, scan_capacity):
         _lib.check(self._L.mij_encoder_reserve_output(self._h, scan_capacity), self._h, "mij_encoder_reserve_output")
+
+    def output_is_uncached(self):
+        """True when reserve_output gave this handle a device-uncached output buffer (the sharded path: peers write into it)."""
+        return bool(self._L.mij_output_is_uncached(self._h))
 
     def output_buffer(self):
         """(device pointer of the output buffer, offset of the scan area inside it, capacity of the scan area)."""
@@ -274,11 +279,12 @@ def ipc_close(d_ptr):
     _lib.load().mij_ipc_close(C.c_void_p(d_ptr))
 
 
-def residual_device(d_a, d_b, d_out, nbytes, mode, stream=0):
-    """mode -1: out = clip(a - b + 128); mode +1: out = clip(a + b - 128) (difference-map compression)."""
+def residual_device(d_a, d_b, d_out, nbytes, mode, stream=0, gain=1):
+    """mode -1: out = clip((a - b) * gain + 128); mode +1: out = clip(a + (b - 128) / gain, halves up) (difference-map compression,
+    SURVEY.md 8a A9; gain: mij_secondary_params)."""
     L = _lib.load()
-    _lib.check(L.mij_residual_device(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out), nbytes, mode, C.c_void_p(stream)), None,
-               "mij_residual_device")
+    _lib.check(L.mij_residual_gain_device(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out), nbytes, mode, int(gain), C.c_void_p(stream)), None,
+               "mij_residual_gain_device")
 
 
 class _PinnedBlock:
@@ -409,35 +415,39 @@ class NvjpegCompressRunner:
             print("[INFO] NvjpegCompressRunner Compress Func Cost Time : %d ms" % int((time.perf_counter() - t0) * 1e3))
         return out, (0 if not out else 1)
 
-    def secondaryCompress(self, image):
+    def secondaryCompress(self, image, quality2=None, css2=None, gain=1):
         """Secondary ("difference map") compression, reference README.md:8: returns (primary, secondary, run_state) where
-        primary = JPEG(image) and secondary = JPEG(clip(image - decode(primary) + 128)). Needs both environments."""
+        primary = JPEG(image) and secondary = JPEG(clip((image - decode(primary)) * gain + 128)) coded at `quality2` / `css2`
+        (default: the first layer's; mij_secondary_params in mi_jpeg.h). Needs the compress environment only: decode(primary)
+        comes from the encoder's own coefficients."""
         try:
-            if self._enc is None or self._dec is None:
-                raise MiJpegError("secondaryCompress() needs buildCompressEnv() and buildDecodeEnv()")
+            if self._enc is None:
+                raise MiJpegError("secondaryCompress() before buildCompressEnv()")
             image = np.ascontiguousarray(image, np.uint8)
             if image.shape != (self.height, self.width, 3):
                 raise MiJpegError("image must be uint8 %dx%dx3" % (self.height, self.width))
+            sp = _lib.SecondaryParams(0 if quality2 is None else quality2, -1 if css2 is None else _css_value(css2), gain)
             # a residual image is close to noise: a layer can exceed the raw size (MIJ_ERR_OVERFLOW reports what is needed)
             cap1 = cap2 = image.size // 2 + 65536
             L = self._enc._L
             for _ in range(4):
                 b1, b2 = np.empty(cap1, np.uint8), np.empty(cap2, np.uint8)
                 n1, n2 = C.c_size_t(cap1), C.c_size_t(cap2)
-                rc = L.mij_secondary_encode_host(self._enc._h, self._dec._h, image.ctypes.data, self.width * 3, 0, _FMT["bgr"],
-                                                 b1.ctypes.data, C.byref(n1), b2.ctypes.data, C.byref(n2))
+                rc = L.mij_secondary_encode_host_ex(self._enc._h, C.byref(sp), image.ctypes.data, self.width * 3, 0, _FMT["bgr"],
+                                                    b1.ctypes.data, C.byref(n1), b2.ctypes.data, C.byref(n2))
                 if rc != -5:    # MIJ_ERR_OVERFLOW
                     break
                 cap1 = max(cap1, n1.value + n1.value // 8 + 4096)
                 cap2 = max(cap2, n2.value + n2.value // 8 + 4096, cap1 if n2.value == 0 else 0)
-            _lib.check(rc, self._enc._h, "mij_secondary_encode_host")
+            _lib.check(rc, self._enc._h, "mij_secondary_encode_host_ex")
             return b1[:n1.value].tobytes(), b2[:n2.value].tobytes(), 1
         except MiJpegError as e:
             print("[ERROR] Exception caught: %s" % e)
             return b"", b"", 0
 
-    def secondaryDecode(self, primary, secondary):
-        """(primary, secondary) -> (H x W x 3 uint8 BGR, run_state): clip(decode(primary) + decode(secondary) - 128)."""
+    def secondaryDecode(self, primary, secondary, gain=1):
+        """(primary, secondary) -> (H x W x 3 uint8 BGR, run_state): clip(decode(primary) + (decode(secondary) - 128) / gain), with the
+        gain the pair was written with."""
         try:
             if self._dec is None:
                 raise MiJpegError("secondaryDecode() before buildDecodeEnv()")
@@ -445,9 +455,10 @@ class NvjpegCompressRunner:
             out = np.empty((inf["height"], inf["width"], 3), np.uint8)
             p1, p2 = np.frombuffer(primary, np.uint8), np.frombuffer(secondary, np.uint8)
             w, h = C.c_int(), C.c_int()
-            self._dec._check(self._dec._L.mij_secondary_decode_host(self._dec._h, p1.ctypes.data, len(primary), p2.ctypes.data, len(secondary),
-                                                                    out.ctypes.data, inf["width"] * 3, _FMT["bgr"], C.byref(w), C.byref(h)),
-                             "mij_secondary_decode_host")
+            sp = _lib.SecondaryParams(0, -1, gain)
+            self._dec._check(self._dec._L.mij_secondary_decode_host_ex(self._dec._h, C.byref(sp), p1.ctypes.data, len(primary), p2.ctypes.data,
+                                                                       len(secondary), out.ctypes.data, inf["width"] * 3, _FMT["bgr"],
+                                                                       C.byref(w), C.byref(h)), "mij_secondary_decode_host_ex")
             return out, 1
         except MiJpegError as e:
             print("[ERROR] Exception caught: %s" % e)

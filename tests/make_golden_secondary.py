@@ -1,0 +1,54 @@
+"""Regenerates tests/golden/big_secondary_8320x40000.json: fingerprints of the second layer of the two-layer ("difference map")
+scheme at the full size when it is coded with parameters of its own (mij_secondary_params): J1 = libjpeg-compatible encode of the
+synthetic image at q95 4:2:2 (the headline file, CRC 47e0cdfa), D = what a stock decoder (libjpeg-turbo through Pillow) makes
+of J1, R = clip((I - D) * gain + 128), J2 = encode(R; quality2, css2) by the CPU oracle. CPU only, ~6 minutes."""
+import io
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import oracle as O  # noqa: E402
+
+W, H = 8320, 40000
+CASES = [("q98_css0_gain1", 98, 0, 1, 64)]     # (key, quality2, css2, gain, the restart interval MIJ_RESTART_AUTO picks for css2)
+
+
+def main():
+    Image.MAX_IMAGE_PIXELS = None
+    img = np.empty((H, W, 3), np.uint8)
+    for y in range(0, H, 4000):
+        img[y:y + 4000] = O.synth_rgb(W, H, y0=y, rows=4000)
+    j1 = O.encode(img, 95, 1, True, 64)
+    assert "%08x" % zlib.crc32(j1) == "47e0cdfa", "the first layer is not the headline file"
+    d = np.asarray(Image.open(io.BytesIO(j1)).convert("RGB"))
+    out = {"first_layer": {"len": len(j1), "crc32": "%08x" % zlib.crc32(j1)}, "cases": {}}
+    for key, q2, css2, gain, ri2 in CASES:
+        r = np.empty_like(img)
+        for y in range(0, H, 2000):
+            r[y:y + 2000] = np.clip((img[y:y + 2000].astype(np.int32) - d[y:y + 2000].astype(np.int32)) * gain + 128, 0, 255).astype(np.uint8)
+        j2 = O.encode(r, q2, css2, True, ri2)
+        d2 = np.asarray(Image.open(io.BytesIO(j2)).convert("RGB"))
+        se1 = se2 = 0.0
+        sh = gain.bit_length() - 1
+        for y in range(0, H, 2000):
+            a = img[y:y + 2000].astype(np.int32)
+            dd = d[y:y + 2000].astype(np.int32)
+            rec = np.clip(dd + ((d2[y:y + 2000].astype(np.int32) - 128 + (gain >> 1)) >> sh), 0, 255)
+            se1 += float(((a - dd) ** 2).sum())
+            se2 += float(((a - rec) ** 2).sum())
+        n = 3.0 * W * H
+        out["cases"][key] = {"len": len(j2), "crc32": "%08x" % zlib.crc32(j2), "residual_crc32": "%08x" % zlib.crc32(r.tobytes()),
+                             "psnr_first_layer": round(10 * np.log10(255.0 ** 2 / (se1 / n)), 3),
+                             "psnr_both_layers": round(10 * np.log10(255.0 ** 2 / (se2 / n)), 3)}
+        print(key, out["cases"][key], flush=True)
+    json.dump(out, open(os.path.join(HERE, "golden", "big_secondary_8320x40000.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

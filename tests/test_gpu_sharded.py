@@ -184,6 +184,31 @@ def test_hip_strips_five_ranks_uneven(oracle, tmp_path):
     assert len(got) == len(want) and zlib.crc32(got) == zlib.crc32(want)
 
 
+def test_reserved_output_buffer_is_uncached_and_still_exact(oracle):
+    """mij_encoder_reserve_output (what every strip-owning rank calls before it exports its buffer) allocates device-uncached
+    memory: peers write into that buffer behind this GPU's caches, so none of its lines may live in them.
+    Header (K3), compaction (K6), the device-side result and the copy to the host all work on it unchanged; MIJ_SHARED_OUT=cached
+    keeps plain memory (child process: the switch is read per call, the assertion is the point)."""
+    import subprocess
+    import nvjpeg_imagecompressor_amd as mij
+    from nvjpeg_imagecompressor_amd import sharded
+    W, H = 1040, 512
+    img = oracle.synth_rgb(W, H)
+    with mij.Encoder(W, H, 92, True, 1) as enc:
+        assert not enc.output_is_uncached()
+        enc.reserve_output(8 * sharded.full_scan_capacity(enc.geometry))
+        assert enc.output_is_uncached()
+        h = mij.encoder.ipc_export(enc.output_buffer()[0])        # exportable: what open_file_targets does next
+        assert len(h) == 64
+        for _ in range(3):
+            got = enc.encode_host(img, "rgb")
+            assert got == oracle.encode(img, 92, 1, True, enc.geometry["restart_interval"])
+    code = ("import sys; sys.path.insert(0, %r); import nvjpeg_imagecompressor_amd as mij\n"
+            "e = mij.Encoder(1040, 512, 92, True, 1); e.reserve_output(1 << 24); assert not e.output_is_uncached(); print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MIJ_SHARED_OUT="cached"), timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def _bench(args, env_extra=None, launcher=False, timeout=900):
     import json
     import subprocess

@@ -239,6 +239,10 @@ MIJ_API int mij_decode_sync(mij_decoder *dec, float *device_ms);
  * "=> Decode Cost time", ImageCompressorImpl.cu:368-373, where the start event is never recorded), and the handle's device. */
 MIJ_API int mij_decode_last_ms(const mij_decoder *dec, float *device_ms);
 MIJ_API int mij_decoder_device(const mij_decoder *dec);
+/* Progressive files without restart markers (round 4): how many scans of the last decode the parallel decoder (first scans by
+ * subsequence synchronisation, AC refinement scans by hypothesis search + exact verification) was tried on, and how many of those
+ * it decoded; the rest were walked by one wave each (exact as well, orders of magnitude slower). Waits for the decode. */
+MIJ_API int mij_decode_px_report(mij_decoder *dec, int *scans_tried, int *scans_parallel);
 /* DecodeWorker end to end (ImageCompressorImpl.cu:311-385): host JPEG bytes -> host pixels (one D2H, already interleaved). */
 MIJ_API int mij_decode_host(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t *dst, size_t pitch,
                             int output_format, int *width, int *height);

@@ -27,7 +27,7 @@ EXPORTS = (
     "mij_secondary_encode_host", "mij_secondary_decode_host", "mij_decode_last_ms", "mij_decoder_device",
     "mij_geometry_query", "mij_encode_entropy_sizes", "mij_encode_place", "mij_sharded_result", "mij_encoder_reserve_output",
     "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close", "mij_place_times", "mij_encode_residual_device",
-    "mij_clock_probe_device", "mij_secondary_encode_host_ex", "mij_secondary_decode_host_ex", "mij_encode_residual_gain_device", "mij_residual_gain_device", "mij_output_is_uncached",
+    "mij_clock_probe_device", "mij_secondary_encode_host_ex", "mij_secondary_decode_host_ex", "mij_encode_residual_gain_device", "mij_residual_gain_device", "mij_output_is_uncached", "mij_decode_px_report",
 )
 
 
@@ -152,6 +152,7 @@ def load():
     L.mij_decoder_last_error.restype = C.c_char_p
     ip = C.POINTER(C.c_int)
     L.mij_decode_info.argtypes = [vp, sz, ip, ip, ip, ip]
+    L.mij_decode_px_report.argtypes = [vp, ip, ip]
     L.mij_decode_device.argtypes = [vp, vp, sz, vp, sz, sz, C.c_int, vp]
     L.mij_decode_sync.argtypes = [vp, C.POINTER(C.c_float)]
     L.mij_decode_host.argtypes = [vp, vp, sz, vp, sz, C.c_int, ip, ip]

@@ -30,6 +30,9 @@ struct mij_decoder {
   unsigned long long *d_scan_ws = nullptr; size_t scan_ws_cap = 0;
   unsigned long long *d_clean_len = nullptr;             // fast route: length of the clean stream
   uint8_t *d_clean = nullptr; size_t clean_cap = 0;      // un-stuffed copies of the scans that have no restart markers (k_decode_wave.inc)
+  uint8_t *d_px_ws = nullptr; size_t px_ws_cap = 0;      // workspaces of the parallel progressive decoder (k_decode_prog.inc), one per scan
+  uint32_t *d_px_flags = nullptr; size_t px_flags_cap = 0;   // four words per scan
+  std::vector<int> px_scans;                                  // last decode: kind of every scan the parallel decoder was tried on (0: not tried)
   hipStream_t aux[4]{};
   std::vector<hipEvent_t> scan_ev;
   hipEvent_t ev_ready{};
@@ -277,7 +280,7 @@ void mij_decoder_destroy(mij_decoder *d) {
   if (d->issued) (void)hipStreamSynchronize(d->last_stream);
   (void)hipFree(d->d_scan); (void)hipFree(d->d_coef); (void)hipFree(d->d_planes); (void)hipFree(d->d_tab);
   (void)hipFree(d->d_seg_pos); (void)hipFree(d->d_chunk_cnt); (void)hipFree(d->d_chunk_base); (void)hipFree(d->d_flags);
-  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws); (void)hipFree(d->d_clean); (void)hipFree(d->d_clean_len);
+  (void)hipFree(d->d_res); (void)hipFree(d->d_out); (void)hipFree(d->d_out2); (void)hipFree(d->d_tabs); (void)hipFree(d->d_par_ws); (void)hipFree(d->d_scan_ws); (void)hipFree(d->d_clean); (void)hipFree(d->d_clean_len); (void)hipFree(d->d_px_ws); (void)hipFree(d->d_px_flags);
   if (d->aux_ok) { for (auto &q : d->aux) (void)hipStreamDestroy(q); (void)hipEventDestroy(d->ev_ready); }
   for (auto &v : d->scan_ev) (void)hipEventDestroy(v);
   if (d->ev_ok) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
@@ -443,6 +446,18 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     }
     if ((rc = ensure(d, d->d_scan_ws, d->scan_ws_cap, words))) return rc;
     if (clean_bytes && (rc = ensure(d, d->d_clean, d->clean_cap, clean_bytes))) return rc;
+    // progressive scans without restart markers: the parallel decoder (k_decode_prog.inc) goes first, each scan with a workspace
+    // of its own (scans run concurrently); the wave decoder is its fallback, decided on the device
+    std::vector<size_t> o_px(ps.scans.size(), (size_t)-1);
+    size_t px_bytes = 0;
+    for (size_t i = 0; i < ps.scans.size(); i++) {
+      const ScanInfo &sc = ps.scans[i];
+      if (ps.progressive && sc.sd.ri == 0 && !lanes_only && px_supported(sc.sd)) {
+        o_px[i] = px_bytes;
+        px_bytes += (px_workspace_bytes(sc.sd, g, sc.len) + 511) & ~(size_t)255;
+      }
+    }
+    if (px_bytes && ((rc = ensure(d, d->d_px_ws, d->px_ws_cap, px_bytes)) || (rc = ensure(d, d->d_px_flags, d->px_flags_cap, 4 * ps.scans.size())))) return rc;
     DHIP(d, hipEventRecord(d->ev_ready, s));
     for (auto &q : d->aux) DHIP(d, hipStreamWaitEvent(q, d->ev_ready, 0));
     for (size_t i = 0; i < ps.scans.size(); i++) {
@@ -467,8 +482,13 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
       unsigned long long *seg = d->d_scan_ws + o_seg[i];
       if (sc.sd.ri == 0 && !lanes_only) {
         // no restart markers: the scan is one chain of symbols -- a whole wave walks it (k_decode_wave.inc)
+        bool same_dc = true;         // a DC scan whose components share one Huffman table parses the same whatever the block-in-MCU
+        for (int c = 1; c < sc.sd.ncomp; c++)
+          same_dc = same_dc && (sc.sd.td[c] == sc.sd.td[0] || memcmp(sc.tab.look[sc.sd.td[c]], sc.tab.look[sc.sd.td[0]], sizeof sc.tab.look[0]) == 0);
+        const bool px = o_px[i] != (size_t)-1;
         DHIP(d, launch_scan_decode_wave(g, sc.sd, base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], d->d_scan_ws + o_len[i],
-                                        d->d_clean + o_clean[i], d->d_tabs + i, d->d_coef, d->d_flags, d->d_res, d->d_flags + 1, q));
+                                        d->d_clean + o_clean[i], d->d_tabs + i, d->d_coef, d->d_flags, d->d_res, d->d_flags + 1, q,
+                                        px ? d->d_px_ws + o_px[i] : nullptr, px ? d->d_px_flags + 4 * i : nullptr, same_dc));
       } else {
         if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], seg, ns, d->d_flags, d->d_res, q));
         else DHIP(d, hipMemsetAsync(seg, 0, sizeof(unsigned long long), q));
@@ -478,6 +498,20 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
     }
     for (size_t i = 0; i < ps.scans.size(); i++) DHIP(d, hipStreamWaitEvent(s, d->scan_ev[i], 0));
     d_final = d->d_tabs + (ps.scans.size() - 1);
+    if (px_bytes) {
+      // which scans did the parallel progressive decoder take? (mij_decode_px_report; MIJ_PX_DEBUG=1 prints it)
+      d->px_scans.assign(ps.scans.size(), 0);
+      for (size_t i = 0; i < ps.scans.size(); i++) d->px_scans[i] = o_px[i] != (size_t)-1 ? ps.scans[i].sd.kind : 0;
+      static const bool dbg = getenv("MIJ_PX_DEBUG") != nullptr;
+      if (dbg) {
+        DHIP(d, hipStreamSynchronize(s));
+        std::vector<uint32_t> f(4 * ps.scans.size());
+        DHIP(d, hipMemcpy(f.data(), d->d_px_flags, f.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ps.scans.size(); i++)
+          if (d->px_scans[i]) fprintf(stderr, "[px] scan %zu kind %d Ss %d Se %d Al %d bytes %zu: %s (unresolved anchors %u, anchors found wrong %d)\n", i, ps.scans[i].sd.kind, ps.scans[i].sd.Ss,
+                                      ps.scans[i].sd.Se, ps.scans[i].sd.Al, ps.scans[i].len, f[4 * i] ? "FELL BACK to the wave decoder" : "parallel", f[4 * i + 2], (int)f[4 * i + 3]);
+      }
+    } else d->px_scans.clear();
   }
   uint8_t *py = d->d_planes, *pcb = py + ysz, *pcr = pcb + csz;
   if (idct_color_supported(g, output_format)) DHIP(d, launch_idct_color(g, d->d_coef, d_final, nullptr, dc_fix, (uint8_t *)d_dst, pitch, output_format, s));
@@ -511,6 +545,23 @@ int mij_decode_last_ms(const mij_decoder *d, float *device_ms) {
 }
 
 int mij_decoder_device(const mij_decoder *d) { return d ? d->device : -1; }
+
+int mij_decode_px_report(mij_decoder *d, int *scans_tried, int *scans_parallel) {
+  if (!d) return MIJ_ERR_INVALID_ARG;
+  if (!d->issued) return dfail(d, MIJ_ERR_NOT_READY, "no decode has been issued on this handle");
+  DHIP(d, hipSetDevice(d->device));
+  DHIP(d, hipStreamSynchronize(d->last_stream));
+  int tried = 0, par = 0;
+  if (!d->px_scans.empty()) {
+    std::vector<uint32_t> f(4 * d->px_scans.size());
+    DHIP(d, hipMemcpy(f.data(), d->d_px_flags, f.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < d->px_scans.size(); i++)
+      if (d->px_scans[i]) { tried++; if (!f[4 * i]) par++; }
+  }
+  if (scans_tried) *scans_tried = tried;
+  if (scans_parallel) *scans_parallel = par;
+  return MIJ_OK;
+}
 
 int mij_decode_host(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t *dst, size_t pitch, int output_format, int *width,
                     int *height) {

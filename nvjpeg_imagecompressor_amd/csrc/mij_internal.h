@@ -162,9 +162,16 @@ struct ScanDesc {
 
 hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, const unsigned long long *seg_pos,
                               long long nseg, const DecTables *tab, int16_t *coef, uint32_t *err_flag, hipStream_t s);
+// px_ws / px_flags (may be null): workspace (px_workspace_bytes) and four device words for the parallel progressive decoder
+// (k_decode_prog.inc), which then goes first; the wave is its fallback, decided on the device.
 hipError_t launch_scan_decode_wave(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, unsigned long long *cnt,
                                    unsigned long long *base, unsigned long long *clean_len, uint8_t *clean, const DecTables *tab,
-                                   int16_t *coef, uint32_t *scratch_flag, DeviceResult *scratch_res, uint32_t *err_flag, hipStream_t s);
+                                   int16_t *coef, uint32_t *scratch_flag, DeviceResult *scratch_res, uint32_t *err_flag, hipStream_t s,
+                                   uint8_t *px_ws = nullptr, uint32_t *px_flags = nullptr, bool same_dc_tables = false);
+size_t px_workspace_bytes(const ScanDesc &sd, const Geom &g, size_t raw_len);
+bool px_supported(const ScanDesc &sd);
+hipError_t launch_px_scan(const Geom &g, const ScanDesc &sd, const uint8_t *clean, const unsigned long long *clean_len, size_t raw_len,
+                          const DecTables *tab, int16_t *coef, uint8_t *ws, uint32_t *flags, bool same_dc_tables, hipStream_t s);
 // Progressive scans (k_encode_prog.inc): gather != 0 counts symbols into hist (4 x 257), otherwise writes the interval slots.
 hipError_t launch_prog_encode(const Geom &g, const ScanDesc &sd, int gather, const int16_t *coef, const DeviceTables *tab, uint8_t *scratch,
                               size_t slot_bytes, uint32_t *seg_bytes, uint32_t *seg_ff, uint32_t *hist, long long nseg, hipStream_t s,

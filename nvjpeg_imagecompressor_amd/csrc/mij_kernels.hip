@@ -15,6 +15,8 @@
 //   D2 k_huff_decode       lane per restart interval (fallback)                                        (k_decode.inc)
 //   D2s k_scan_decode      progressive / multi-scan / greyscale scans, lane per restart interval       (k_decode_scans.inc)
 //   D2w k_scan_decode_wave the same scans when they have NO restart markers: one wave walks the chain   (k_decode_wave.inc)
+//   D2x k_px_*             progressive scans without restart markers IN PARALLEL: first scans by subsequence synchronisation,
+//                          refinement scans by hypothesis search + exact verification; D2w is its fallback (k_decode_prog.inc)
 //   D3 k_idct, D4 k_upsample_color[8], k_residual   IDCT, upsampling + colour, difference map          (k_decode.inc)
 // Bit-identity with stock JPEG codecs means following their integer procedures: the "islow" FDCT / IDCT factorisation and
 // constants, the colour / downsampling rounding rules, the quantiser and the optimal-table and progressive procedures are
@@ -41,5 +43,6 @@ namespace mij {
 #include "k_decode_wave.inc"
 #include "k_decode_par.inc"
 #include "k_launch.inc"
+#include "k_decode_prog.inc"
 
 }  // namespace mij

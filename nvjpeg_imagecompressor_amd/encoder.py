@@ -235,6 +235,12 @@ class Decoder:
         self._check(self._L.mij_decode_device(self._h, C.c_void_p(d_jpeg), nbytes, C.c_void_p(d_ptr), pitch, plane_stride,
                                               _FMT[fmt], C.c_void_p(stream)), "mij_decode_device")
 
+    def px_report(self):
+        """(scans the parallel progressive decoder was tried on, scans it decoded) for the last decode (mij_decode_px_report)."""
+        a, b = C.c_int(), C.c_int()
+        self._check(self._L.mij_decode_px_report(self._h, C.byref(a), C.byref(b)), "mij_decode_px_report")
+        return a.value, b.value
+
     def last_ms(self):
         ms = C.c_float()
         self._check(self._L.mij_decode_last_ms(self._h, C.byref(ms)), "mij_decode_last_ms")

@@ -79,3 +79,116 @@ def test_progressive_medium_image(mij, oracle):
     jpg = _save(img, quality=90, subsampling=1, progressive=True, optimize=True)
     with mij.Decoder() as dec:
         assert np.array_equal(dec.decode_host(jpg, "rgb"), _pil_dec(jpg))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Progressive files WITHOUT restart markers through the parallel decoder (k_decode_prog.inc, round 4): first scans by subsequence
+# synchronisation, AC refinement scans by hypothesis search over the history maps + exact verification, the wave decoder of
+# k_decode_wave.inc as the on-device fallback. Whatever route a scan takes, the pixels are libjpeg-turbo's.
+# ---------------------------------------------------------------------------------------------------------------------
+def _grey_save(g, **kw):
+    b = io.BytesIO()
+    Image.fromarray(g, "L").save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("ss", [0, 1, 2, "grey"])
+@pytest.mark.parametrize("size,q", [((1234, 777), 95), ((2080, 1536), 96), ((3000, 520), 92), ((520, 3000), 98)])
+def test_progressive_without_restart_markers_in_parallel(mij, oracle, ss, size, q):
+    """Images large enough for several anchors per refinement scan (2,048 blocks apart) and hundreds of subsequences per first scan,
+    all samplings Pillow can write and greyscale. On this dense content (noise + texture at q >= 92) the parallel decoder must take
+    every scan it is tried on: a silent fall-back to the wave decoder would still be exact, and a hundred times slower."""
+    W, H = size
+    img = oracle.synth_rgb(W, H)
+    if ss == "grey":
+        jpg = _grey_save(img[..., 1], quality=q, progressive=True, optimize=True)
+    else:
+        jpg = _save(img, quality=q, subsampling=ss, progressive=True, optimize=True)
+    assert b"\xff\xc2" in jpg and b"\xff\xdd" not in jpg            # SOF2, no DRI
+    with mij.Decoder() as dec:
+        got = dec.decode_host(jpg, "rgb")
+        tried, parallel = dec.px_report()
+        assert np.array_equal(got, _pil_dec(jpg))
+        assert tried >= 5 and parallel == tried, (tried, parallel)
+        assert np.array_equal(dec.decode_host(jpg, "bgr"), _pil_dec(jpg)[..., ::-1])       # and again on the same handle
+
+
+def test_progressive_fallback_is_decided_per_scan_and_exact(mij, oracle):
+    """Smooth content: the history maps of the refinement scans are nearly empty, almost every hypothesis parses without a violation
+    and no anchor is unanimous -- those scans go to the wave decoder (on the device, no host decision), the first scans still run
+    in parallel. Same pixels either way."""
+    yy, xx = np.mgrid[0:900, 0:1400]
+    smooth = np.stack([(xx * 255 // 1400), (yy * 255 // 900), ((xx + yy) * 255 // 2300)], -1).astype(np.uint8)
+    jpg = _save(smooth, quality=90, subsampling=2, progressive=True, optimize=True)
+    with mij.Decoder() as dec:
+        got = dec.decode_host(jpg, "rgb")
+        tried, parallel = dec.px_report()
+        assert np.array_equal(got, _pil_dec(jpg))
+        assert tried >= 9 and 5 <= parallel <= tried
+    # spectral selection only (no successive approximation: no refinement scans at all): IJG's scan script is not reachable through
+    # Pillow, but a quality-100 greyscale file has Al = 0 first scans of every band plus refinements; covered above. Flat image:
+    flat = np.full((800, 1200, 3), 128, np.uint8)
+    flat[200:600, 300:900] = (250, 20, 20)
+    jpg = _save(flat, quality=85, subsampling=1, progressive=True)
+    with mij.Decoder() as dec:
+        assert np.array_equal(dec.decode_host(jpg, "rgb"), _pil_dec(jpg))          # long end-of-band runs across subsequences
+
+
+def test_progressive_parallel_switches():
+    """MIJ_PROG_PARALLEL=0 keeps rounds 2-3's wave decoder for every scan, MIJ_PX_LANE_REFINE=1 the first (lane per segment) form of
+    the verify pass: all three give libjpeg-turbo's pixels. The switches are read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import io, sys, numpy as np
+from PIL import Image, ImageFile
+ImageFile.MAXBLOCK = 1 << 26
+sys.path.insert(0, %r)
+import nvjpeg_imagecompressor_amd as mij
+from oracle import oracle as O
+img = O.synth_rgb(1234, 777)
+with mij.Decoder() as dec:
+    for kw in (dict(quality=95, subsampling=1), dict(quality=97, subsampling=2)):
+        b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", progressive=True, optimize=True, **kw); j = b.getvalue()
+        assert np.array_equal(dec.decode_host(j, "rgb"), np.asarray(Image.open(io.BytesIO(j)).convert("RGB")))
+        print("report", dec.px_report())
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env, want in (({"MIJ_PROG_PARALLEL": "0"}, "report (0, 0)"), ({"MIJ_PX_LANE_REFINE": "1"}, "report (9, 9)"), ({}, "report (9, 9)")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout and want in r.stdout, (env, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_fullsize_progressive_file_without_restart_markers(mij):
+    """Round 3's criterion: a libjpeg-turbo PROGRESSIVE 8320x40000 q95 4:2:2 file with NO DRI -- the reference's own output format
+    (ImageCompressorImpl.cu:28) at its headline size -- decodes pixel-identically, device resident, in a fraction of a second
+    (rounds 2-3: ~80 s, one wave per scan). Pillow writes the file here (~10 s); its CRC and the CRC of the decoded image are the
+    committed golden (tests/golden/prog_nodri_8320x40000.json, from tools/decode_prog_nodri_fullsize.py)."""
+    import json
+    import os
+    import zlib
+    import torch
+    ImageFile.MAXBLOCK = 1 << 30
+    Image.MAX_IMAGE_PIXELS = None
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prog_nodri_8320x40000.json")))
+    W, H = 8320, 40000
+    d_img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    mij.synth_image_device(d_img.data_ptr(), W, 0, H, W * 3, bgr=False)
+    torch.cuda.synchronize()
+    b = io.BytesIO()
+    Image.fromarray(d_img.cpu().numpy()).save(b, "JPEG", quality=95, subsampling=1, progressive=True, optimize=True)
+    jpg = b.getvalue()
+    assert (len(jpg), "%08x" % zlib.crc32(jpg)) == (gold["file_bytes"], gold["file_crc32"])
+    d_file = torch.frombuffer(bytearray(jpg), dtype=torch.uint8).cuda()
+    d_out = torch.empty_like(d_img)
+    with mij.Decoder() as dec:
+        ms = []
+        for _ in range(3):
+            dec.decode_device_ptr(d_file.data_ptr(), len(jpg), d_out.data_ptr(), W * 3, "rgb")
+            ms.append(dec.sync())
+        tried, parallel = dec.px_report()
+    assert "%08x" % zlib.crc32(d_out.cpu().numpy().tobytes()) == gold["decoded_crc32"]      # = Pillow's own decode of the file
+    assert (tried, parallel) == (9, 9)
+    assert min(ms) < 1000.0, ms                 # (measured ~0.2 s; the bound only says "not the serial route": that one takes ~80 s)
+    print("full-size progressive no-DRI decode: %s ms" % ["%.1f" % m for m in ms])

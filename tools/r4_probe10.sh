@@ -29,8 +29,14 @@ if t:
         byq[q][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); byq[q][1] += 1
     for q, (ns, n) in byq.items():
         print(" queue %s: %.2f ms busy in %d kernels" % (q, ns / 1e6, n))
-    big = sorted(half, key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))[:14]
-    for r in big:
-        print("  %8.2f ms at %8.2f ms q%s %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, (int(r["Start_Timestamp"]) - t0) / 1e6, r["Queue_Id"], r["Kernel_Name"][:70]))
+    qmax = max(byq, key=lambda q: byq[q][0])
+    seq = [r for r in half if r["Queue_Id"] == qmax]
+    lines = []
+    for r in seq:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        if d >= 0.25:
+            lines.append("  %8.2f ms at %8.2f ms %s grid %s" % (d, (int(r["Start_Timestamp"]) - t0) / 1e6, r["Kernel_Name"].split("(")[0][-28:], r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
+    open(O + "/busiest_queue_sequence.txt", "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:140]))
 PY
 rm -rf $O/prof

@@ -42,7 +42,14 @@ struct DeviceTables {
   uint8_t vals[4][256];
   uint32_t nvals[4];
   uint32_t lut[LUT_SIZE]; // (code << 5) | length, indexed LUT_xx + symbol
+  // K4's coding table in its final form (round 4), written once per image by K3: entry = ((codelen + nb) << 27) | (code << nb) for
+  // symbol (run << 4) | nb at word run * 24 + nb * 2 + (chroma ? 1 : 0) (384 words, nb = 0 columns zero), then the DC entries at
+  // 384 + nb * 2 + chroma (32 words), then EOB luma / chroma, ZRL luma / chroma (416..419). Every K4 workgroup used to rebuild
+  // these 416 words from `lut` (seven scattered loads, a convert, a store, per restart interval: 40,625 times per image); now
+  // it copies them with two 16-byte loads per lane.
+  __attribute__((aligned(16))) uint32_t tok[448];
 };
+constexpr int TOK_DC = 384, TOK_EOB = 416, TOK_ZRL = 418;
 
 struct DeviceResult {     // written by the scan kernel, copied to pinned host memory
   uint64_t scan_bytes;

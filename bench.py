@@ -373,8 +373,13 @@ def _smi_clocks():
     import re
     import subprocess
     out = {}
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        # under rocprofv3 the profiler's preloaded library initialises the GPU in every process it is inherited by, and rocm-smi is a
+        # script (env -> python3): that chain of exec()s from GPU-initialised processes is what the GPU boxes refuse
+        return {"note": "not queried under a profiler"}
     try:
-        r = subprocess.run(["rocm-smi", "--showclocks", "--showmaxpower", "--showpower", "--showperflevel"], capture_output=True, text=True, timeout=20)
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showmaxpower", "--showpower", "--showperflevel"], capture_output=True, text=True, timeout=20, env=env)
         for key, pat in (("sclk_MHz", r"GPU\[0\].*sclk clock level.*\((\d+)Mhz\)"), ("mclk_MHz", r"GPU\[0\].*mclk clock level.*\((\d+)Mhz\)"),
                          ("power_cap_W", r"GPU\[0\].*Max Graphics Package Power \(W\):\s*([\d.]+)"),
                          ("socket_power_W", r"GPU\[0\].*Current Socket Graphics Package Power \(W\):\s*([\d.]+)"),
@@ -1021,7 +1026,8 @@ def measured_traffic(kernel, args, optimize, world, lib_hash):
         return None, "%s was taken on another build of the library (%s...): not quoted" % (rel, str(d.get("library_source_hash"))[:12])
     k = d.get("kernels", {}).get(kernel)
     if k and "valu_wave_instructions" in k:
-        _VALU[kernel] = {kk: vv["valu_wave_instructions"] for kk, vv in d["kernels"].items() if "valu_wave_instructions" in vv}
+        # (the headline path's kernels only: k_transform_nostats is the stage-A-alone pass, not part of an image's step)
+        _VALU[kernel] = {kk: vv["valu_wave_instructions"] for kk, vv in d["kernels"].items() if "valu_wave_instructions" in vv and kk != "k_transform_nostats"}
     return (k["total_bytes"], rel) if k else (None, None)
 
 

@@ -165,3 +165,55 @@ def test_plain_command_line_needs_no_launcher():
     # -X importtime is a flag of the PARENT interpreter only (the children are started without it): its import log is the parent's
     imported = [l.split("|")[-1].strip() for l in r.stderr.splitlines() if l.startswith("import time:")]
     assert imported and "torch" not in imported and "nvjpeg_imagecompressor_amd" not in imported
+
+
+# ---- round 4: pieces of the one-GPU line that need no GPU ---------------------------------------------------------------
+class _A:
+    loop, two_streams, tables_ahead, progressive = None, False, None, False
+
+
+def test_one_gpu_loop_selection():
+    import importlib
+    b = importlib.import_module("bench")
+    a = _A()
+    assert b._one_gpu_loop(a, True) == "overlap" and b._one_gpu_loop(a, False) == "overlap"          # the default, fixed tables too
+    a.two_streams = True
+    assert b._one_gpu_loop(a, True) == "two-streams"
+    a.two_streams, a.tables_ahead = False, False
+    assert b._one_gpu_loop(a, True) == "one-stream"
+    a.tables_ahead = True
+    assert b._one_gpu_loop(a, True) == "tables-ahead" and b._one_gpu_loop(a, False) == "one-stream"  # nothing to build ahead with fixed tables
+    a.loop = "tables-ahead"
+    a.progressive = True
+    assert b._one_gpu_loop(a, True) == "progressive"
+
+
+def test_cpu_legs_compare_the_whole_file_by_fingerprint(monkeypatch):
+    """cpu_baseline_fields: libjpeg-turbo's whole-image file (one core, same run) against the GPU's by CRC + length; a partial
+    one-core sample claims nothing."""
+    import importlib
+    b = importlib.import_module("bench")
+    cb = {"turbo": {"value": 600.0, "unit": "Mpixels/s", "cores": 16, "bytes": 1, "sample": "s"},
+          "turbo_1core": {"value": 60.0, "unit": "Mpixels/s", "cores": 1, "bytes": 203772997, "crc32": "47e0cdfa", "whole_image": True, "sample": "s"},
+          "port": {"value": 300.0, "unit": "Mpixels/s", "cores": 16, "bytes": 1, "sample": "s"}}
+    monkeypatch.setattr(b, "cpu_baselines", lambda args, optimize, ri: cb)
+    out = b.cpu_baseline_fields(None, True, 64, "47e0cdfa", 203772997)
+    assert out["turbo_file_identical"] is True and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline_1core"]["crc32"] == "47e0cdfa"
+    assert b.cpu_baseline_fields(None, True, 64, "deadbeef", 203772997)["turbo_file_identical"] is False
+    cb["turbo_1core"]["whole_image"] = False
+    assert "turbo_file_identical" not in b.cpu_baseline_fields(None, True, 64, "47e0cdfa", 203772997)
+
+
+def test_supervisor_adds_the_cpu_legs_at_n_gt_1(bench, capsys, monkeypatch):
+    """N > 1: the children never run the CPU legs (they hold the GPUs); the supervisor does, after they are gone."""
+    monkeypatch.setattr(bench, "cpu_baseline_fields", lambda args, optimize, ri, crc, nbytes: {"cpu_baseline": {"value": 1.0, "kind": "port", "crc_seen": crc}})
+    child = CHILD.replace('print(json.dumps({"value": 1.0, "n_gpus": world, "config": {"gather": mode}}), flush=True)',
+                          'print(json.dumps({"value": 1.0, "n_gpus": world, "jpeg_crc32": "47e0cdfa", "jpeg_bytes": 5, "config": {"gather": mode, "restart_interval": 64}}), flush=True)')
+    import pathlib
+    script = pathlib.Path(bench._log).parent / "child2.py"
+    script.write_text(child)
+    monkeypatch.setattr(bench, "_child_argv", lambda mode: [sys.executable, str(script), mode])
+    rc, line, log = _run(bench, capsys, {}, monkeypatch, world=2, no_cpu_baseline=False, no_optimize=False, gather="sendrecv")
+    assert rc == 0 and line["cpu_baseline"]["crc_seen"] == "47e0cdfa"
+    rc, line, log = _run(bench, capsys, {}, monkeypatch, world=2, no_cpu_baseline=True, no_optimize=False, gather="sendrecv")
+    assert rc == 0 and "cpu_baseline" not in line

@@ -213,10 +213,17 @@ MIJ_API int mij_debug_tables(mij_encoder *enc, uint8_t *host_dst_4x273);
  *  - One interleaved sequential scan (this library's output, camera files): decoded in parallel -- every restart interval
  *    is further cut into 1-KiB subsequences that are decoded speculatively and synchronised (k_decode_par.inc), so a file
  *    WITHOUT restart markers is as fast as one with them.
- *  - Progressive and multi-scan files: exact, one GPU lane per restart interval of each scan (k_decode_scans.inc);
- *    without restart markers one WAVE per scan (k_decode_wave.inc: the bitstream is inherently serial, the wave's 64 lanes
- *    share the byte unstuffing, the refill and the refinement of a block) -- fine for pictures, seconds for hundreds of
- *    megapixels.
+ *  - Progressive and multi-scan files WITH restart markers: exact, one GPU lane per restart interval of each scan
+ *    (k_decode_scans.inc).
+ *  - Progressive files WITHOUT restart markers (what the reference's encoder writes, ImageCompressorImpl.cu:256-259): each
+ *    scan in parallel (k_decode_prog.inc). DC-first and AC-first scans synchronise like a sequential scan (the state of the
+ *    decoder is the bit position and the place in the MCU / the EOB run). An AC refinement scan does not synchronise by
+ *    itself -- how many correction bits a block takes depends on which of its coefficients are already non-zero -- so block
+ *    positions are FOUND: hypotheses "block b starts at bit p" are walked against the history maps and die on a
+ *    violation, survivors that agree unanimously become anchors, and the scan is then decoded exactly from anchor to anchor,
+ *    each segment having to arrive on the next anchor bit-exactly. A scan where this finds nothing to hold on to (smooth
+ *    content, thin histories) is walked by one WAVE instead (k_decode_wave.inc: exact as well, orders of magnitude slower:
+ *    seconds for hundreds of megapixels); mij_decode_px_report says which scans went which way.
  * Pixels are identical to libjpeg-turbo's (islow IDCT, fancy upsampling). */
 typedef struct mij_decoder mij_decoder;
 /* initDecodeEnv (ImageCompressorImpl.cu:67-95) / destoryDecodeEnv (.cu:97-117). NULL destroy is a no-op. */

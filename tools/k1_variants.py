@@ -37,6 +37,13 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "nz_from_size": {"MIJ_K1_NZ_FROM_SIZE": 1},
     "noflush": {"MIJ_K1_NOFLUSH": 1},
     "nt_stores": {"MIJ_K1_NT_STORES": 1},
+    # round 4: rows 0..3 of the next pass requested before phase 2 (default on)
+    "no_prefetch": {"MIJ_K1_PREFETCH": 0},
+    "lds444": {"MIJ_K1_444_REGS": 0},            # 4:4:4 chroma through LDS (rounds 1-3)
+    "lds444_no_prefetch": {"MIJ_K1_444_REGS": 0, "MIJ_K1_PREFETCH": 0},
+    "copies444_7": {"MIJ_HIST_COPIES_444": 7},
+    "copies444_8": {"MIJ_HIST_COPIES_444": 8},
+    "copies444_6": {"MIJ_HIST_COPIES_444": 6},
 }
 if os.environ.get("MIJ_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["MIJ_VARIANTS"].split(",")}

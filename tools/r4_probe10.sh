@@ -34,9 +34,9 @@ if t:
     lines = []
     for r in seq:
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-        if d >= 0.25:
+        if d >= float(os.environ.get("TL_MIN_MS", "0.25")):
             lines.append("  %8.2f ms at %8.2f ms %s grid %s" % (d, (int(r["Start_Timestamp"]) - t0) / 1e6, r["Kernel_Name"].split("(")[0][-28:], r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
     open(O + "/busiest_queue_sequence.txt", "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:140]))
+    print("\n".join(lines[:500]))
 PY
 rm -rf $O/prof

@@ -31,7 +31,7 @@ struct mij_decoder {
   unsigned long long *d_clean_len = nullptr;             // fast route: length of the clean stream
   uint8_t *d_clean = nullptr; size_t clean_cap = 0;      // un-stuffed copies of the scans that have no restart markers (k_decode_wave.inc)
   uint8_t *d_px_ws = nullptr; size_t px_ws_cap = 0;      // workspaces of the parallel progressive decoder (k_decode_prog.inc), one per scan
-  uint32_t *d_px_flags = nullptr; size_t px_flags_cap = 0;   // four words per scan
+  uint32_t *d_px_flags = nullptr; size_t px_flags_cap = 0;   // PX_FLAG_WORDS words per scan
   std::vector<int> px_scans;                                  // last decode: kind of every scan the parallel decoder was tried on (0: not tried)
   hipStream_t aux[4]{};
   std::vector<hipEvent_t> scan_ev;
@@ -457,7 +457,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
         px_bytes += (px_workspace_bytes(sc.sd, g, sc.len) + 511) & ~(size_t)255;
       }
     }
-    if (px_bytes && ((rc = ensure(d, d->d_px_ws, d->px_ws_cap, px_bytes)) || (rc = ensure(d, d->d_px_flags, d->px_flags_cap, 4 * ps.scans.size())))) return rc;
+    if (px_bytes && ((rc = ensure(d, d->d_px_ws, d->px_ws_cap, px_bytes)) || (rc = ensure(d, d->d_px_flags, d->px_flags_cap, 4 * PX_FLAG_WORDS * ps.scans.size())))) return rc;
     DHIP(d, hipEventRecord(d->ev_ready, s));
     for (auto &q : d->aux) DHIP(d, hipStreamWaitEvent(q, d->ev_ready, 0));
     for (size_t i = 0; i < ps.scans.size(); i++) {
@@ -488,7 +488,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
         const bool px = o_px[i] != (size_t)-1;
         DHIP(d, launch_scan_decode_wave(g, sc.sd, base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], d->d_scan_ws + o_len[i],
                                         d->d_clean + o_clean[i], d->d_tabs + i, d->d_coef, d->d_flags, d->d_res, d->d_flags + 1, q,
-                                        px ? d->d_px_ws + o_px[i] : nullptr, px ? d->d_px_flags + 4 * i : nullptr, same_dc));
+                                        px ? d->d_px_ws + o_px[i] : nullptr, px ? d->d_px_flags + PX_FLAG_WORDS * i : nullptr, same_dc));
       } else {
         if (sc.sd.ri > 0) DHIP(d, launch_find_restarts(base, sc.len, d->d_scan_ws + o_cnt[i], d->d_scan_ws + o_base[i], seg, ns, d->d_flags, d->d_res, q));
         else DHIP(d, hipMemsetAsync(seg, 0, sizeof(unsigned long long), q));
@@ -505,11 +505,15 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
       static const bool dbg = getenv("MIJ_PX_DEBUG") != nullptr;
       if (dbg) {
         DHIP(d, hipStreamSynchronize(s));
-        std::vector<uint32_t> f(4 * ps.scans.size());
+        std::vector<uint32_t> f(PX_FLAG_WORDS * ps.scans.size());
         DHIP(d, hipMemcpy(f.data(), d->d_px_flags, f.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < ps.scans.size(); i++)
-          if (d->px_scans[i]) fprintf(stderr, "[px] scan %zu kind %d Ss %d Se %d Al %d bytes %zu: %s (unresolved anchors %u, anchors found wrong %d)\n", i, ps.scans[i].sd.kind, ps.scans[i].sd.Ss,
-                                      ps.scans[i].sd.Se, ps.scans[i].sd.Al, ps.scans[i].len, f[4 * i] ? "FELL BACK to the wave decoder" : "parallel", f[4 * i + 2], (int)f[4 * i + 3]);
+        for (size_t i = 0; i < ps.scans.size(); i++) {
+          if (!d->px_scans[i]) continue;
+          const uint32_t *fi = f.data() + PX_FLAG_WORDS * i;
+          fprintf(stderr, "[px] scan %zu kind %d Ss %d Se %d Al %d bytes %zu: %s (unresolved anchors %u, anchors found wrong %d)\n", i, ps.scans[i].sd.kind, ps.scans[i].sd.Ss,
+                  ps.scans[i].sd.Se, ps.scans[i].sd.Al, ps.scans[i].len, fi[0] ? "FELL BACK to the wave decoder" : "parallel", fi[2], (int)fi[3]);
+          if (d->px_scans[i] == 4 && fi[4]) fprintf(stderr, "[px]        candidate lists written %u, anchors the chain decided %u\n", fi[4], fi[5]);
+        }
       }
     } else d->px_scans.clear();
   }
@@ -553,10 +557,10 @@ int mij_decode_px_report(mij_decoder *d, int *scans_tried, int *scans_parallel) 
   DHIP(d, hipStreamSynchronize(d->last_stream));
   int tried = 0, par = 0;
   if (!d->px_scans.empty()) {
-    std::vector<uint32_t> f(4 * d->px_scans.size());
+    std::vector<uint32_t> f(PX_FLAG_WORDS * d->px_scans.size());
     DHIP(d, hipMemcpy(f.data(), d->d_px_flags, f.size() * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < d->px_scans.size(); i++)
-      if (d->px_scans[i]) { tried++; if (!f[4 * i]) par++; }
+      if (d->px_scans[i]) { tried++; if (!f[PX_FLAG_WORDS * i]) par++; }
   }
   if (scans_tried) *scans_tried = tried;
   if (scans_parallel) *scans_parallel = par;

@@ -114,6 +114,21 @@ def test_progressive_without_restart_markers_in_parallel(mij, oracle, ss, size, 
         assert np.array_equal(dec.decode_host(jpg, "bgr"), _pil_dec(jpg)[..., ::-1])       # and again on the same handle
 
 
+@pytest.mark.parametrize("size,q,ss", [((1234, 777), 75, 1), ((1040, 512), 75, 1), ((1040, 512), 90, 2)])
+def test_progressive_thin_history_anchors_are_decided_by_the_chain(mij, oracle, size, q, ss):
+    """Lower qualities: the history maps are thin, the paths that run a whole number of blocks beside the true one meet no violation
+    and few anchors are unanimous. Their survivors stay on as candidates and the state the anchor before arrives at picks the true
+    one (k_px_prewalk / k_px_chain); before that these files sent 3-4 of their 9 scans to the wave decoder."""
+    img = oracle.synth_rgb(*size)
+    jpg = _save(img, quality=q, subsampling=ss, progressive=True, optimize=True)
+    assert b"\xff\xc2" in jpg and b"\xff\xdd" not in jpg
+    with mij.Decoder() as dec:
+        got = dec.decode_host(jpg, "rgb")
+        tried, parallel = dec.px_report()
+        assert np.array_equal(got, _pil_dec(jpg))
+        assert tried == 9 and parallel == tried, (tried, parallel)
+
+
 def test_progressive_fallback_is_decided_per_scan_and_exact(mij, oracle):
     """Smooth content: the history maps of the refinement scans are nearly empty, almost every hypothesis parses without a violation
     and no anchor is unanimous -- those scans go to the wave decoder (on the device, no host decision), the first scans still run

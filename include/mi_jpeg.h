@@ -221,8 +221,10 @@ MIJ_API int mij_debug_tables(mij_encoder *enc, uint8_t *host_dst_4x273);
  *    itself -- how many correction bits a block takes depends on which of its coefficients are already non-zero -- so block
  *    positions are FOUND: hypotheses "block b starts at bit p" are walked against the history maps and die on a
  *    violation, survivors that agree unanimously become anchors, and the scan is then decoded exactly from anchor to anchor,
- *    each segment having to arrive on the next anchor bit-exactly. A scan where this finds nothing to hold on to (smooth
- *    content, thin histories) is walked by one WAVE instead (k_decode_wave.inc: exact as well, orders of magnitude slower:
+ *    each segment having to arrive on the next anchor bit-exactly. Where the survivors do not agree (thin histories: the
+ *    paths a whole number of blocks beside the true one meet no violation either) they stay on as candidates and the state
+ *    the anchor before ARRIVES at picks the true one. A scan where all this finds nothing to hold on to (the thinnest scans of
+ *    large smooth images, scans of a few hundred bytes) is walked by one WAVE instead (k_decode_wave.inc: exact as well, orders of magnitude slower:
  *    seconds for hundreds of megapixels); mij_decode_px_report says which scans went which way.
  * Pixels are identical to libjpeg-turbo's (islow IDCT, fancy upsampling). */
 typedef struct mij_decoder mij_decoder;

@@ -15,6 +15,13 @@ for src, dst in pairs:
         shutil.copy(s, os.path.join(P, "r04_" + dst)); print("copied", src)
     else:
         print("MISSING", src)
+tl = os.path.join(G, "r4refresh/px_timeline.txt")
+if os.path.exists(tl):
+    body = open(tl).read()
+    open(os.path.join(P, "r04_decode_progressive_kernel_stats.txt"), "w").write(
+        "rocprofv3 --kernel-trace --stats over tools/decode_prog_nodri_fullsize.py 40000 2 nocheck (tools/r4_probe10.sh, final library of round 4):\n"
+        "per-kernel totals over both decodes, then the second decode's kernels (>= 0.25 ms) on its busiest queue = the luma chain\n" + body)
+    print("copied px_timeline")
 for pat, dst in (("prof_bench/**/*kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_bench_one/**/*kernel_stats.csv", "bench_kernel_stats_one_stream_loop.csv"),
                  ("pmc_fetch/**/*counter_collection.csv", "pmc_fetch_size.csv"), ("pmc_write/**/*counter_collection.csv", "pmc_write_size.csv")):
     fs = glob.glob(os.path.join(G, pat), recursive=True)
@@ -32,11 +39,11 @@ if t:
     for key, name in (("k_transform<2, 1, true, true>", "k_transform (with statistics)"), ("k_encode<", "k_encode"), ("k_compact", "k_compact"), ("k_transform<2, 1, true, false>", "k_transform without statistics (stage A alone)")):
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]]
         if key.endswith("false>"):
-            sel, which = d[2:], "stage-A pass: all launches but the 2 warm-up ones"
+            sel, which = d[4:], "stage-A pass: all launches but the 4 warm-up ones"
         elif "k_transform" in key:
             sel, which = d[-15:-5], "per-kernel pass: its 10 timed launches (one image at a time on one stream, after the timed loop; the 5 launches behind them are the single-image timings)"
-        else:      # behind the per-kernel pass these kernels also run 12 times in the stage-A pass (fixed-table encoder) and 5 times in the single-image timings
-            sel, which = d[-27:-17], "per-kernel pass: its 10 timed launches (one image at a time on one stream, after the timed loop)"
+        else:      # behind the per-kernel pass these kernels also run 14 times in the stage-A pass (fixed-table encoder) and 5 times in the single-image timings
+            sel, which = d[-29:-19], "per-kernel pass: its 10 timed launches (one image at a time on one stream, after the timed loop)"
         if sel:
             out.append('"%s",%d,%.1f,%.1f,%.1f,"%s"' % (name, len(sel), sum(sel) / len(sel), min(sel), max(sel), which))
         if d:

@@ -36,4 +36,5 @@ step "decode: own full-size file";   timeout -k 10 300 python3 tools/decode_full
 step "decode: progressive no-DRI full size"; timeout -k 10 600 python3 tools/decode_prog_nodri_fullsize.py 40000 5 2>/dev/null | tail -1 > $O/decode_prog_nodri_fullsize.json || exit 1
 step "config 5";                     timeout -k 10 300 python3 tools/secondary_fullsize.py 2>/dev/null | tail -1 > $O/secondary_fullsize.json || exit 1
 step "px cases";                     timeout -k 10 600 python3 tools/r4_px_test.py 2>/dev/null | grep -v "^\[px" > $O/px_cases.txt
+step "progressive decode: kernel timeline"; TL_MIN_MS=0.25 bash tools/r4_probe10.sh > $O/px_timeline.txt 2>&1
 step done

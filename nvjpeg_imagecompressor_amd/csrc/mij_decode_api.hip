@@ -512,7 +512,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
           const uint32_t *fi = f.data() + PX_FLAG_WORDS * i;
           fprintf(stderr, "[px] scan %zu kind %d Ss %d Se %d Al %d bytes %zu: %s (unresolved anchors %u, anchors found wrong %d)\n", i, ps.scans[i].sd.kind, ps.scans[i].sd.Ss,
                   ps.scans[i].sd.Se, ps.scans[i].sd.Al, ps.scans[i].len, fi[0] ? "FELL BACK to the wave decoder" : "parallel", fi[2], (int)fi[3]);
-          if (d->px_scans[i] == 4 && fi[4]) fprintf(stderr, "[px]        candidate lists written %u, anchors the chain decided %u\n", fi[4], fi[5]);
+          if (d->px_scans[i] == 4 && fi[4]) fprintf(stderr, "[px]        candidate lists written %u, anchors the chain decided among candidates %u, adopted %u\n", fi[4], fi[5], fi[8]);
         }
       }
     } else d->px_scans.clear();

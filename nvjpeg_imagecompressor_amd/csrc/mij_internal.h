@@ -175,7 +175,7 @@ hipError_t launch_scan_decode_wave(const Geom &g, const ScanDesc &sd, const uint
                                    unsigned long long *base, unsigned long long *clean_len, uint8_t *clean, const DecTables *tab,
                                    int16_t *coef, uint32_t *scratch_flag, DeviceResult *scratch_res, uint32_t *err_flag, hipStream_t s,
                                    uint8_t *px_ws = nullptr, uint32_t *px_flags = nullptr, bool same_dc_tables = false);
-constexpr int PX_FLAG_WORDS = 8;     // device words of one scan's parallel progressive decode (k_decode_prog.inc): [0] fell back, [1] pass changed, [2..5] diagnostics
+constexpr int PX_FLAG_WORDS = 12;     // device words of one scan's parallel progressive decode (k_decode_prog.inc): [0] fell back, [1] pass changed, [2..8] diagnostics / gates
 size_t px_workspace_bytes(const ScanDesc &sd, const Geom &g, size_t raw_len);
 bool px_supported(const ScanDesc &sd);
 hipError_t launch_px_scan(const Geom &g, const ScanDesc &sd, const uint8_t *clean, const unsigned long long *clean_len, size_t raw_len,

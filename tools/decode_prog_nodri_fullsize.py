@@ -13,13 +13,15 @@ ImageFile.MAXBLOCK = 1 << 30
 W, H = 8320, int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 check = (sys.argv[3] != "nocheck") if len(sys.argv) > 3 else True
+Q = int(sys.argv[4]) if len(sys.argv) > 4 else 95             # quality and Pillow's subsampling code (0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0) of the file
+SS = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 d_img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
 mij.synth_image_device(d_img.data_ptr(), W, 0, H, W * 3, bgr=False)
 torch.cuda.synchronize()
 img = d_img.cpu().numpy()
 t0 = time.perf_counter()
 b = io.BytesIO()
-Image.fromarray(img).save(b, "JPEG", quality=95, subsampling=1, progressive=True, optimize=True)
+Image.fromarray(img).save(b, "JPEG", quality=Q, subsampling=SS, progressive=True, optimize=True)
 j = b.getvalue()
 t_enc = time.perf_counter() - t0
 print("##progress encoded %d bytes in %.1f s" % (len(j), t_enc), flush=True)
@@ -32,7 +34,7 @@ with mij.Decoder() as dec:
         ms.append(round(dec.sync(), 2))
         print("##progress rep %d: %.2f ms, parallel %s" % (r, ms[-1], dec.px_report()), flush=True)
     tried, par = dec.px_report()
-out = {"file": "libjpeg-turbo (Pillow) progressive, no DRI, %dx%d q95 4:2:2" % (W, H), "file_bytes": len(j), "file_crc32": "%08x" % zlib.crc32(j),
+out = {"file": "libjpeg-turbo (Pillow) progressive, no DRI, %dx%d q%d %s" % (W, H, Q, {0: "4:4:4", 1: "4:2:2", 2: "4:2:0"}[SS]), "file_bytes": len(j), "file_crc32": "%08x" % zlib.crc32(j),
        "device_ms": ms, "device_ms_median": sorted(ms)[len(ms) // 2], "scans_tried": tried, "scans_parallel": par, "pillow_encode_s": round(t_enc, 1),
        "library_source_hash": mij.library_source_hash()}
 got = d_out.cpu().numpy()

@@ -41,6 +41,7 @@ VARIANTS = {   # experiment switches of k_common.inc / k_transform.inc; "default
     "no_prefetch": {"MIJ_K1_PREFETCH": 0},
     "lds444": {"MIJ_K1_444_REGS": 0},            # 4:4:4 chroma through LDS (rounds 1-3)
     "lds444_no_prefetch": {"MIJ_K1_444_REGS": 0, "MIJ_K1_PREFETCH": 0},
+    "no_pk_fma": {"MIJ_K1_PK_FMA": 0},            # colour conversion with scalar FMAs (rounds 1-4a)
     "px_g1024": {"MIJ_PX_G": 1024},
     "px_g512": {"MIJ_PX_G": 512},
     "copies444_7": {"MIJ_HIST_COPIES_444": 7},

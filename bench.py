@@ -459,10 +459,12 @@ def worker_one_gpu(args):
 
     # the stage-A pass's encoder (fixed tables) is made here: allocating its workspace between the passes below would idle the device
     # for long enough that the clock falls back (seen: 0.448 ms average over launches whose fastest took 0.414)
-    ea = sa = None
+    ea = sa = ea2 = sa2 = None
     if args.stage_a_pass > 0 and not args.progressive and optimize:
         ea = sharded.make_hip_strip_encoder(torch, W, H, args.quality, False, args.css, 0, 1, 0, args.fmt, restart_interval=args.restart_interval)
         sa = sharded.HipStripEncoder(torch, ea, d_img, args.fmt, shared_statistics=False)
+        ea2 = sharded.make_hip_strip_encoder(torch, W, H, args.quality, False, args.css, 0, 1, 0, args.fmt, restart_interval=args.restart_interval)
+        sa2 = sharded.HipStripEncoder(torch, ea2, d_img, args.fmt, shared_statistics=False)
     for _ in range(args.warmup):
         step()
     drain()
@@ -500,17 +502,37 @@ def worker_one_gpu(args):
     jpeg_keep = jpeg_t.clone()
 
     # ---- per-kernel pass: every kernel of an image alone on ONE stream, events around each (the library's own, mij_stage_times) ----
+    # (Two handles take turns on the ONE stream: image i + 1 is enqueued before the host waits for image i, so the device never idles
+    # between the images -- with one handle it did, ~50 us per image, and over a dozen images the clock started to fall: 2.42 -> 2.35 GHz
+    # measured behind the stage-A pass -- while every kernel still runs alone, one behind the other on the same stream.)
+    def alone_pass(pairs, count, warm, collect):
+        n, total, out = len(pairs), count + warm, None
+        for e, _ in pairs:
+            e.enable_timing(True)
+        pairs[0][1].issue_whole(main)
+        issued = 1
+        for i in range(total):
+            if n > 1 and issued < total:
+                pairs[issued % n][1].issue_whole(main)
+                issued += 1
+            e, st = pairs[i % n]
+            out = st.finish_whole()
+            if i >= warm:
+                collect(e.stage_times())
+            if n == 1 and issued < total:
+                st.issue_whole(main)
+                issued += 1
+        for e, _ in pairs:
+            e.enable_timing(False)
+        return out
+
     stage_acc = {}
     kp = max(1, args.kernel_pass)
-    encs[0].enable_timing(True)
-    jpeg_kp = None
-    for i in range(kp + 2):
-        strips[0].issue_whole(main)
-        jpeg_kp = strips[0].finish_whole()
-        if i >= 2:
-            for k, v in encs[0].stage_times().items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
-    encs[0].enable_timing(False)
+
+    def add_stages(t):
+        for k, v in t.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    jpeg_kp = alone_pass(list(zip(encs, strips))[:2], kp, 2, add_stages)
     stages = {k: v / kp for k, v in stage_acc.items()}
     jpeg_kp = jpeg_kp.clone()            # fingerprinted in report(): a 204-MB copy to the host here would let the clock fall back
     clocks.append(_clock(torch, mij, "after the per-kernel pass"))
@@ -518,18 +540,10 @@ def worker_one_gpu(args):
     # ---- stage A alone: the transform WITHOUT the fused statistics (what a fixed-table encoder runs), same pixels ----
     stage_a = None
     if args.stage_a_pass > 0 and not args.progressive:
-        if not optimize:
-            ea, sa = encs[0], strips[0]
-        ea.enable_timing(True)
-        acc, each = 0.0, []
-        for i in range(args.stage_a_pass + 4):
-            sa.issue_whole(main)
-            sa.finish_whole()
-            if i >= 4:
-                t = ea.stage_times()["transform"]
-                acc += t
-                each.append(t)
-        ea.enable_timing(False)
+        pairs_a = list(zip(encs, strips))[:2] if not optimize else [(ea, sa), (ea2, sa2)]
+        each = []
+        alone_pass(pairs_a, args.stage_a_pass, 4, lambda t: each.append(t["transform"]))
+        acc = sum(each)
         ms_a = acc / args.stage_a_pass
         bytes_a = algorithmic_bytes_per_pixel(args.css, 0.0)["transform"] * rows * W
         stage_a = {"kernel": "k_transform without statistics (fixed-table encoder, same pixels)", "launches": args.stage_a_pass,
@@ -540,7 +554,8 @@ def worker_one_gpu(args):
         clocks.append(_clock(torch, mij, "after the stage-A pass"))
         if optimize:
             ea.close()
-            del sa, ea
+            ea2.close()
+            del sa, ea, sa2, ea2
 
     # ---- one image alone: issue -> complete file (what the reference's one event pair around nvjpegEncodeImage times, .cu:279-291) ----
     lat = []

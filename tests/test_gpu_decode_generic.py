@@ -114,11 +114,13 @@ def test_progressive_without_restart_markers_in_parallel(mij, oracle, ss, size, 
         assert np.array_equal(dec.decode_host(jpg, "bgr"), _pil_dec(jpg)[..., ::-1])       # and again on the same handle
 
 
-@pytest.mark.parametrize("size,q,ss", [((1234, 777), 75, 1), ((1040, 512), 75, 1), ((1040, 512), 90, 2)])
+@pytest.mark.parametrize("size,q,ss", [((1234, 777), 75, 1), ((1040, 512), 75, 1), ((1040, 512), 90, 2), ((8320, 2048), 90, 2), ((8320, 2048), 75, 1)])
 def test_progressive_thin_history_anchors_are_decided_by_the_chain(mij, oracle, size, q, ss):
     """Lower qualities: the history maps are thin, the paths that run a whole number of blocks beside the true one meet no violation
     and few anchors are unanimous. Their survivors stay on as candidates and the state the anchor before arrives at picks the true
-    one (k_px_prewalk / k_px_chain); before that these files sent 3-4 of their 9 scans to the wave decoder."""
+    one (k_px_prewalk / k_px_chain); before that these files sent 3-4 of their 9 scans to the wave decoder. The 17-Mpixel files also
+    need the sweeps (the finest level searching again next to what the chain has decided, with the scan's own fitted bits per block
+    and per history bit) and what the search resolved demoted to candidates."""
     img = oracle.synth_rgb(*size)
     jpg = _save(img, quality=q, subsampling=ss, progressive=True, optimize=True)
     assert b"\xff\xc2" in jpg and b"\xff\xdd" not in jpg

@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--fixed-root", action="store_true", help="N > 1, put gather: rank 0 assembles every file (default: the assembling rank "
                     "rotates from image to image, so that the strips of consecutive images arrive over different GPUs' links)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="one GPU: skip the sections behind the headline passes (`configs.table1` = BASELINE config 3, "
+                    "`configs.secondary` = config 5, `decode` = both decoders); they only run on the default workload anyway")
+    ap.add_argument("--no-progressive-decode", action="store_true", help="skip `decode.progressive_nodri` (Pillow writes the 190-MB progressive file "
+                    "on the host first: ~9 s)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1000, help="rows per CPU-baseline strip (one strip per core)")
     ap.add_argument("--cpu-one-core-rows", type=int, default=0, help="rows of the 1-core CPU sample (0 = the whole image, SURVEY 8d (i))")
@@ -595,9 +599,274 @@ def worker_one_gpu(args):
     if stage_a is not None:
         extra["stage_A_alone"] = stage_a
     extra["_kp_file"] = jpeg_kp
+    extra["untimed_steps"] = args.warmup + settle_steps
+    extra["untimed_steps_note"] = "%d warm-up steps + %d settling steps of the same loop (clock.settle_steps) ran before the timed region" % (args.warmup, settle_steps)
+    default_workload = ((W, H, args.quality, args.css) == (W_IMG, H_IMG, QUALITY, CSS_NAME) and optimize and not args.progressive
+                        and args.restart_interval < 0)
+    if default_workload and not args.no_extra:
+        extra.update(extra_sections(args, torch, mij, sharded, d_img, jpeg_keep, copy_gbs))
     rc = report(args, torch, mij, ctx, extra)
     encs[0].close()
     return rc
+
+
+# =====================================================================================================================
+# Sections behind the headline passes (one GPU, default workload): BASELINE configs 3 and 5 and both decoders, so that the ONE
+# driver-run line carries every single-GPU configuration. Each section is fenced, untimed by `value`, and fails soft (an "error" key).
+# =====================================================================================================================
+def _golden(name):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _psnr_device(torch, a, b, band=4000):
+    """PSNR of two H x W x 3 uint8 device images (integer squared error summed in bands)."""
+    import math
+    se = 0
+    for y in range(0, a.shape[0], band):
+        d = a[y:y + band].to(torch.int32) - b[y:y + band].to(torch.int32)
+        se += int((d * d).sum().item())
+    n = a.numel()
+    return float("inf") if se == 0 else round(10.0 * math.log10(255.0 ** 2 / (se / n)), 3)
+
+
+def _crc_device(t):
+    import numpy as np
+    return "%08x" % zlib.crc32(np.ascontiguousarray(t.cpu().numpy()))
+
+
+def _wall(torch, f, reps=3, warm=1):
+    """Median wall ms of f() fenced by device synchronisation on both sides (what a caller with one image waits for)."""
+    out = []
+    for i in range(warm + reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f()
+        torch.cuda.synchronize()
+        if i >= warm:
+            out.append((time.perf_counter() - t0) * 1e3)
+    return round(sorted(out)[len(out) // 2], 4), [round(x, 4) for x in out]
+
+
+def section_table1(args, torch, mij, sharded, d_img, copy_gbs):
+    """BASELINE config 3 = the reference's table (1) (README.md:45-51): the five samplings at q95, optimised tables, same loop as the headline
+    (transform of image i beside the entropy stage of image i-1, three handles), K1 alone from a one-stream pass with events."""
+    W, H = W_IMG, H_IMG
+    gold = _golden("big_8320x40000_q95.json").get("cases", {})
+    main = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    side_s = side.cuda_stream
+    steps, warm = 20, 10
+    rows = {}
+    out_img = torch.empty_like(d_img)
+    with mij.Decoder() as dec:
+        for css in ("444", "422", "440", "420", "411"):
+            encs = [sharded.make_hip_strip_encoder(torch, W, H, QUALITY, True, css, 0, 1, 0, args.fmt) for _ in range(3)]
+            strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=False) for e in encs]
+            q = []
+
+            def step(i):
+                st = strips[i % 3]
+                st.enc.transform(st.d_img.data_ptr(), st.pitch, st.fmt, 0, main)
+                st.enc.tables(side_s)
+                st.enc.entropy(side_s)
+                q.append(st)
+                return q.pop(0).finish_whole() if len(q) >= 3 else None
+
+            def drain():
+                last = None
+                while q:
+                    last = q.pop(0).finish_whole()
+                return last
+            for i in range(warm):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            f = drain()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            jpg = f.clone()
+            # K1 alone: two handles taking turns on one stream, events around every kernel (the library's own)
+            acc, n_kp = {}, 6
+            for e in encs[:2]:
+                e.enable_timing(True)
+            strips[0].issue_whole(main)
+            for i in range(n_kp + 2):
+                if i + 1 < n_kp + 2:
+                    strips[(i + 1) % 2].issue_whole(main)
+                strips[i % 2].finish_whole()
+                if i >= 2:
+                    for k, v in encs[i % 2].stage_times().items():
+                        acc[k] = acc.get(k, 0.0) + v / n_kp
+            # the file through the library's own decoder (pixel-identical to libjpeg-turbo's by the GPU tests; Pillow cannot be asked for
+            # five 333-Mpixel decodes inside a bench line): PSNR against the source, decode time
+            dms = []
+            for _ in range(3):
+                dec.decode_device_ptr(jpg.data_ptr(), jpg.numel(), out_img.data_ptr(), W * 3, args.fmt)
+                dms.append(dec.sync())
+            ri = encs[0].geometry["restart_interval"]
+            for e in encs:
+                e.close()
+            nbytes = int(jpg.numel())
+            crc = _crc_device(jpg)
+            g = gold.get("css%d_ri%d_opt" % ({"444": 0, "422": 1, "420": 2, "440": 3, "411": 4}[css], ri))
+            bpp = algorithmic_bytes_per_pixel(css, nbytes / (3.0 * W * H))
+            k1 = bpp["transform"] * W * H / (acc["transform"] * 1e-3) / 1e9
+            k4 = bpp["entropy"] * W * H / (acc["entropy"] * 1e-3) / 1e9
+            rows[css] = {"ms_per_step": round(ms, 4), "Mpixels/s": round(W * H / 1e6 / (ms * 1e-3), 1), "steps": steps, "restart_interval": ri,
+                         "jpeg_bytes": nbytes, "ratio": round(nbytes / (3.0 * W * H), 5), "crc32": crc,
+                         "golden_match": (None if g is None else (g["crc32"] == crc and g["len"] == nbytes)),
+                         "psnr_db": _psnr_device(torch, out_img, d_img),
+                         "K1_ms": round(acc["transform"], 4), "K1_frac": round(k1 / HBM_PEAK_GBS, 4),
+                         "K4_ms": round(acc["entropy"], 4), "K4_frac": round(k4 / HBM_PEAK_GBS, 4),
+                         "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+                         "decode_ms": round(sorted(dms)[1], 3)}
+            del strips, encs, jpg, f
+    del out_img
+    torch.cuda.empty_cache()
+    return {"what": "BASELINE config 3 (reference README.md:45-51, table 1): 8320x40000 q95 optimised Huffman at the five samplings; %d timed steps each "
+                    "of the headline's loop after %d warm-up steps; K1 / K4 alone from a one-stream pass of 6 images with hipEvents; golden = "
+                    "tests/golden/big_8320x40000_q95.json (CPU oracle); psnr_db through the library's own decoder" % (steps, warm),
+            "rows": rows}
+
+
+def section_secondary(args, torch, mij, d_img):
+    """BASELINE config 5: encode -> difference map (from the first layer's coefficients) -> encode; and back: decode both, add."""
+    W, H = W_IMG, H_IMG
+    gold = _golden("big_secondary_8320x40000.json")
+    res_img, dec_img, rec_img = torch.empty_like(d_img), torch.empty_like(d_img), torch.empty_like(d_img)
+    n = d_img.numel()
+    out = {"what": "BASELINE config 5 (reference README.md:8): J1 = enc(I); R = clip((I - dec(J1)) * gain + 128) from J1's coefficients; J2 = enc(R); and "
+                   "back: I' = clip(dec(J1) + (dec(J2) - 128) / gain). Wall ms fenced by device synchronisation, median of 3 after one warm-up, "
+                   "everything device resident; golden = tests/golden/big_secondary_8320x40000.json (CPU oracle + libjpeg-turbo's decode)",
+           "first_layer": None, "cases": {}}
+    with mij.Encoder(W, H, QUALITY, True, 1) as e1, mij.Decoder() as dec:
+        r1 = {}
+        for key, q2, css2, gain in (("q95_css1_gain1", 95, 1, 1), ("q98_css0_gain1", 98, 0, 1)):
+            with mij.Encoder(W, H, q2, True, css2) as e2:
+                r2 = {}
+
+                def compress():
+                    e1.encode_device(d_img.data_ptr(), W * 3, args.fmt)
+                    r1.update(e1.result())
+                    e1.residual_device(d_img.data_ptr(), W * 3, res_img.data_ptr(), args.fmt, gain=gain)
+                    e2.encode_device(res_img.data_ptr(), W * 3, args.fmt)
+                    r2.update(e2.result())
+
+                def expand():
+                    dec.decode_device_ptr(r1["d_buffer"] + r1["header_offset"], r1["file_bytes"], dec_img.data_ptr(), W * 3, args.fmt)
+                    dec.sync()
+                    dec.decode_device_ptr(r2["d_buffer"] + r2["header_offset"], r2["file_bytes"], rec_img.data_ptr(), W * 3, args.fmt)
+                    dec.sync()
+                    mij.residual_device(dec_img.data_ptr(), rec_img.data_ptr(), rec_img.data_ptr(), n, +1, gain=gain)
+                c_ms, c_all = _wall(torch, compress)
+                x_ms, x_all = _wall(torch, expand)
+                j2 = e2.retrieve()
+                g = gold.get("cases", {}).get(key)
+                crc2 = "%08x" % zlib.crc32(j2)
+                case = {"quality2": q2, "css2": {0: "444", 1: "422"}[css2], "gain": gain, "secondary_compress_ms": c_ms, "runs_ms": c_all,
+                        "decode_both_and_add_ms": x_ms, "decode_runs_ms": x_all, "round_trip_ms": round(c_ms + x_ms, 4),
+                        "bytes": [r1["file_bytes"], len(j2)], "crc32_second_layer": crc2,
+                        "golden_match": (None if g is None else (g["crc32"] == crc2 and g["len"] == len(j2))),
+                        "psnr_first_layer_db": _psnr_device(torch, dec_img, d_img), "psnr_both_layers_db": _psnr_device(torch, rec_img, d_img)}
+                if g is not None:
+                    case["golden_psnr_db"] = [g.get("psnr_first_layer"), g.get("psnr_both_layers")]
+                out["cases"][key] = case
+        j1 = e1.retrieve()
+        g1 = gold.get("first_layer")
+        crc1 = "%08x" % zlib.crc32(j1)
+        out["first_layer"] = {"bytes": len(j1), "crc32": crc1, "golden_match": (None if not g1 else (g1["crc32"] == crc1 and g1["len"] == len(j1)))}
+    del res_img, dec_img, rec_img
+    torch.cuda.empty_cache()
+    return out
+
+
+def section_decode(args, torch, mij, d_img, d_file, copy_gbs):
+    """A10: the library's decoder on (i) its own full-size headline file, (ii) the reference's format -- libjpeg-turbo's progressive file of the
+    same image without restart markers, written by Pillow on the host in this run."""
+    W, H = W_IMG, H_IMG
+    out = {}
+    d_out = torch.empty_like(d_img)
+    nfile = int(d_file.numel())
+    with mij.Decoder() as dec:
+        ms = []
+        for _ in range(7):
+            dec.decode_device_ptr(d_file.data_ptr(), nfile, d_out.data_ptr(), W * 3, "rgb")
+            ms.append(dec.sync())
+        ms = ms[2:]
+        med = sorted(ms)[len(ms) // 2]
+        alg = nfile + 3 * W * H
+        gbs = alg / (med * 1e-3) / 1e9
+        out["own_file"] = {"file": "the timed region's file (baseline, DRI=64), device resident in and out", "file_bytes": nfile,
+                           "device_ms": round(med, 3), "runs_ms": [round(x, 3) for x in ms], "Mpixels/s": round(W * H / 1e6 / (med * 1e-3), 1),
+                           "decoded_crc32": _crc_device(d_out), "identical_to_pillow": None,
+                           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                        "frac_of_copy_ceiling": round(gbs / copy_gbs, 4) if copy_gbs else None,
+                                        "algorithmic_bytes": alg, "note": "algorithmic bytes = file + 3*W*H pixels written; device time of the whole decode "
+                                        "(mij_decode_sync: events around all its kernels), median of 5 after 2 warm-up decodes. Huffman decoding is "
+                                        "bound by instruction issue / serial dependence, not by HBM (DESIGN.md section 4)"}}
+        if not args.no_progressive_decode:
+            from PIL import Image, ImageFile
+            Image.MAX_IMAGE_PIXELS = None
+            ImageFile.MAXBLOCK = 1 << 30
+            gp = _golden("prog_nodri_8320x40000.json")
+            img = d_img.cpu().numpy()
+            if args.fmt == "bgr":
+                img = img[..., ::-1]
+            t0 = time.perf_counter()
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, "JPEG", quality=QUALITY, subsampling=1, progressive=True, optimize=True)
+            j = b.getvalue()
+            t_enc = time.perf_counter() - t0
+            del img, b
+            d_j = torch.frombuffer(bytearray(j), dtype=torch.uint8).cuda()
+            pms = []
+            for _ in range(4):
+                dec.decode_device_ptr(d_j.data_ptr(), len(j), d_out.data_ptr(), W * 3, "rgb")
+                pms.append(dec.sync())
+            tried, par = dec.px_report()
+            pmed = sorted(pms[1:])[1]
+            crc_f, crc_d = "%08x" % zlib.crc32(j), _crc_device(d_out)
+            out["progressive_nodri"] = {"file": "libjpeg-turbo (Pillow) progressive SOF2, optimised tables, NO restart markers, q95 4:2:2 of the same image "
+                                                "(the reference's nvJPEG output mode, ImageCompressorImpl.cu:28), written on the host in this run",
+                                        "file_bytes": len(j), "file_crc32": crc_f, "pillow_encode_s": round(t_enc, 1),
+                                        "device_ms": round(pmed, 2), "runs_ms": [round(x, 2) for x in pms], "scans_tried": tried, "scans_parallel": par,
+                                        "decoded_crc32": crc_d,
+                                        "golden": {"file_crc32": gp.get("file_crc32"), "decoded_crc32": gp.get("decoded_crc32"),
+                                                   "source": "tests/golden/prog_nodri_8320x40000.json: Pillow's own decode of that file"},
+                                        "golden_match": (None if not gp else (gp.get("file_crc32") == crc_f and gp.get("decoded_crc32") == crc_d)),
+                                        "Mpixels/s": round(W * H / 1e6 / (pmed * 1e-3), 1)}
+            del d_j
+    del d_out
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_sections(args, torch, mij, sharded, d_img, d_file, copy_gbs):
+    out, t_all = {"configs": {}}, time.perf_counter()
+    for name, fn in (("table1", lambda: section_table1(args, torch, mij, sharded, d_img, copy_gbs)),
+                     ("secondary", lambda: section_secondary(args, torch, mij, d_img))):
+        t0 = time.perf_counter()
+        try:
+            out["configs"][name] = fn()
+        except Exception as ex:      # noqa: BLE001 -- the headline stands without a section that failed; the failure is in the line
+            out["configs"][name] = {"error": repr(ex)[:400]}
+        out["configs"][name]["section_wall_s"] = round(time.perf_counter() - t0, 1)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        out["decode"] = section_decode(args, torch, mij, d_img, d_file, copy_gbs)
+    except Exception as ex:          # noqa: BLE001
+        out["decode"] = {"error": repr(ex)[:400]}
+    out["decode"]["section_wall_s"] = round(time.perf_counter() - t0, 1)
+    out["extra_sections_wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
 
 
 def worker_ranks(args):
@@ -951,7 +1220,11 @@ def report(args, torch, mij, c, extra):
         if c["want_put"] and dpipe is None:
             out["gather_note"] = "the output buffers could not be peer-mapped (hipIpc*): every rank took send/recv"
     if not args.no_psnr:
-        out["psnr_db"], out["psnr_note"] = _psnr_check(jpeg, W, H, args.fmt, c["d_img"] if world == 1 else None)
+        out["psnr_db"], out["psnr_note"], pillow_crc = _psnr_check(jpeg, W, H, args.fmt, c["d_img"] if world == 1 else None)
+        own = out.get("decode", {}).get("own_file")
+        if own is not None:        # the library's decode of the timed region's file against libjpeg-turbo's decode of the same file, by CRC of the RGB8 image
+            own["pillow_decoded_crc32"] = pillow_crc
+            own["identical_to_pillow"] = own["decoded_crc32"] == pillow_crc
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_fields(args, optimize, geo["restart_interval"], out["jpeg_crc32"], out["jpeg_bytes"]))
     print(json.dumps(out), flush=True)
@@ -1065,6 +1338,7 @@ def _psnr_check(jpeg, W, H, fmt, d_img):
     Image.MAX_IMAGE_PIXELS = None
     t0 = time.perf_counter()
     dec = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB"))
+    dec_crc = "%08x" % zlib.crc32(memoryview(np.ascontiguousarray(dec)).cast("B"))
     se, band = 0.0, 2000
     for y in range(0, H, band):
         n = min(band, H - y)
@@ -1083,7 +1357,7 @@ def _psnr_check(jpeg, W, H, fmt, d_img):
         se += float((diff * diff).sum())
     mse = se / (3.0 * W * H)
     psnr = float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
-    return round(psnr, 3), "stock decoder: Pillow/libjpeg-turbo, full image, %.1fs" % (time.perf_counter() - t0)
+    return round(psnr, 3), "stock decoder: Pillow/libjpeg-turbo, full image, %.1fs" % (time.perf_counter() - t0), dec_crc
 
 
 if __name__ == "__main__":

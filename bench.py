@@ -1161,17 +1161,41 @@ def report(args, torch, mij, c, extra):
                     "note": ("avg launch duration from hipEvents around the kernel on its stream, %s"
                              % ("in the separate one-stream pass after the timed region (per_kernel_pass)" if world == 1 else "over the timed steps"))}
         if _VALU.get(kname[dom]):
-            # What actually bounds this path: vector instruction issue. At the 3-5 waves per SIMD these
-            # kernels run at, a wave64 vector instruction occupies its SIMD for ~4 cycles; PMC count (same passes, same hash).
+            # What bounds this path: vector instruction issue. A BOUND, not a floor of 4 cycles per instruction (rounds 3-4: K4
+            # already ran under that one): the dynamic count is SQ_INSTS_VALU (PMC pass, same library hash), the cost per instruction the
+            # class mix of the kernel's ISA -- 2 cycles for v_add/sub_u32, logic, v_ashrrev_i32, moves and scalar-width f32 add / mul / fma, 4 for the
+            # rest (tools/valu_bound.py, rates measured by tools/valu_rate.hip) -- on 1,024 SIMDs at the clock measured around the timed region.
             n = _VALU[kname[dom]]
             mhz = clock_mhz or 2400.0
-            sm = 1024 * mhz * 1e6 / 4.0         # wave-instructions per second: 1,024 SIMDs, 4 cycles each
-            roofline["valu_issue"] = {"wave_instructions": n[kname[dom]], "clock_MHz": round(mhz, 1),
+            classes = valu_classes(lib_hash)
+            short = {v: k for k, v in kname.items()}
+            per, bound_all, flat_all = {}, 0.0, 0.0
+            for kn, cnt in n.items():
+                cpi = (classes.get(kn) or {}).get("cycles_per_vector_instruction_bound")
+                st = short.get(kn)
+                ms_k = stages.get(st) if st else None
+                e = {"wave_instructions": cnt}
+                if cpi:
+                    e["bound_cycles_per_instruction"] = cpi
+                    e["bound_ms"] = round(cnt * cpi / (1024 * mhz * 1e6) * 1e3, 4)
+                    e["share_4_cycle"] = classes[kn].get("share_4_cycle")
+                    bound_all += e["bound_ms"]
+                if ms_k:
+                    e["launch_ms"] = round(ms_k, 4)
+                    e["cycles_per_valu_instruction"] = round(ms_k * 1e-3 * 1024 * mhz * 1e6 / cnt, 3)       # measured: launch time x SIMDs x clock / count
+                    if cpi:
+                        e["bound_frac_of_launch"] = round(e["bound_ms"] / ms_k, 3)
+                flat_all += cnt * 4.0 / (1024 * mhz * 1e6) * 1e3
+                per[kn] = e
+            roofline["valu_issue"] = {"model": "bound" if classes else "flat 4 cycles per instruction (no class file for this build: an upper estimate, not a bound)",
+                                      "clock_MHz": round(mhz, 1),
                                       "clock_source": "measured around the timed region (clock.probes)" if clock_mhz else "assumed",
-                                      "floor_ms": round(n[kname[dom]] / sm * 1e3, 4),
-                                      "frac_of_launch": round(n[kname[dom]] / sm * 1e3 / stage_roof[dom]["ms"], 3),
-                                      "all_kernels_floor_ms": round(sum(n.values()) / sm * 1e3, 4),
-                                      "note": "SQ_INSTS_VALU per launch x 4 cycles / (1,024 SIMDs x clock): the step is bound by vector issue, not by HBM"}
+                                      "kernels": per, "all_kernels_bound_ms": round(bound_all, 4) if classes else None,
+                                      "all_kernels_at_4_cycles_ms": round(flat_all, 4),
+                                      "classes_source": classes.get("_source"),
+                                      "note": "bound_ms = SQ_INSTS_VALU x (2 x share_2 + 4 x share_4 + 8 x share_8) / (1,024 SIMDs x clock); cycles_per_valu_instruction = "
+                                              "what the launch actually spent per vector instruction. Their ratio is what is left to an ideal schedule of the "
+                                              "SAME instructions (every 2-cycle slot filled by a second wave); fewer instructions move the bound itself"}
         if dom == "transform" and optimize:
             # K1 also takes the AC statistics (SURVEY 8d stage B, a separate 2(1+f) B/px read in an unfused design);
             # against stage A + B's algorithmic bytes, as SURVEY 8d prescribes for a fused kernel:
@@ -1329,6 +1353,25 @@ def measured_traffic(kernel, args, optimize, world, lib_hash):
 
 
 _VALU = {}
+
+
+def valu_classes(lib_hash):
+    """Per-kernel class mix of the vector instructions from profiles/r*_valu_classes.json (tools/valu_bound.py), only if it was made from
+    the sources of the library loaded now."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_classes.json")))
+    if not files:
+        return {}
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    if d.get("library_source_hash") != lib_hash:
+        return {}
+    out = dict(d.get("kernels", {}))
+    out["_source"] = os.path.relpath(files[-1], ROOT)
+    return out
 
 
 def _psnr_check(jpeg, W, H, fmt, d_img):

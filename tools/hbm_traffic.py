@@ -59,6 +59,10 @@ def main():
     valu = {}
     if len(sys.argv) > 3 and logged_hash(sys.argv[3]) == h_f:
         valu, _ = per_kernel(sys.argv[3], "SQ_INSTS_VALU")
+    # optional fourth pass (tools/pmc_pass.sh a SQ_WAVES ...): waves per launch (tools/valu_bound.py solves a kernel's loop trip count from both)
+    nwaves = {}
+    if len(sys.argv) > 4 and logged_hash(sys.argv[4]) == h_f:
+        nwaves, _ = per_kernel(sys.argv[4], "SQ_WAVES")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         fb = int(fetch.get(k, 0.0) * 1024 * 2)
@@ -66,6 +70,8 @@ def main():
         kernels[k] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "launches_averaged": [nf.get(k, 0), nw.get(k, 0)]}
         if k in valu:
             kernels[k]["valu_wave_instructions"] = int(valu[k])
+        if k in nwaves:
+            kernels[k]["waves"] = int(nwaves[k])
     print(json.dumps({
         "library_source_hash": h_f,
         "workload": "8320x40000 q95 4:2:2 optimised, AUTO restart interval (64 MCUs), 1 GPU (bench.py defaults)",

@@ -252,6 +252,12 @@ MIJ_API int mij_decoder_device(const mij_decoder *dec);
  * subsequence synchronisation, AC refinement scans by hypothesis search + exact verification) was tried on, and how many of those
  * it decoded; the rest were walked by one wave each (exact as well, orders of magnitude slower). Waits for the decode. */
 MIJ_API int mij_decode_px_report(mij_decoder *dec, int *scans_tried, int *scans_parallel);
+/* Footprint of that parallel decoder: its workspace is sized by the FILE and kept in the handle -- per AC refinement scan two hypothesis
+ * lists of 16 bytes x max(8 M, what the scan's anchors can ask for; at most 2^28) entries plus ~60 bytes per block: about 0.3 GB for a
+ * 1920x1080 file, ~2.5 GB per luma refinement scan of 8320x40000, all scans of a file together. It is never a reason for a decode to fail:
+ * above MIJ_PX_WS_BUDGET_MB (environment, default 24576 = 24 GiB; 0 = never use the parallel decoder's workspace) or when the device
+ * refuses the allocation, the largest scans are walked by one wave each instead (exact, no workspace, slower) until the rest fits.
+ * MIJ_PROG_PARALLEL=0 turns the parallel decoder off altogether. */
 /* DecodeWorker end to end (ImageCompressorImpl.cu:311-385): host JPEG bytes -> host pixels (one D2H, already interleaved). */
 MIJ_API int mij_decode_host(mij_decoder *dec, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t *dst, size_t pitch,
                             int output_format, int *width, int *height);
@@ -296,7 +302,12 @@ MIJ_API int mij_secondary_decode_host(mij_decoder *dec, const uint8_t *primary, 
  * bit for bit. The second layer is coded by a second encoder handle kept inside `enc` (created on first use, re-created when
  * quality2 / css2 change, destroyed with `enc`), with the restart interval MIJ_RESTART_AUTO picks for its sampling. Each
  * layer is an ordinary JFIF file: byte-identical to what a stock encoder makes of I / of R at that layer's settings. The
- * gain is not stored in either file: the caller passes the same params to the decode side (only `gain` is read there). */
+ * gain is not stored in either file: the caller passes the same params to the decode side (only `gain` is read there).
+ * Footprint: that second handle owns a complete set of encoder workspaces of its own (coefficients 2(1+f) bytes per pixel, entropy
+ * scratch and output buffer: roughly 4 GB for 8320x40000 at 4:4:4), kept until `enc` is destroyed or the parameters change; with
+ * quality2 / css2 left at the first layer's values no second handle exists and nothing extra is held. If it cannot be created the call
+ * fails with mij_encoder_create's own code and message (MIJ_ERR_ALLOC: "... hipMalloc ..."). Both layers are coded on one stream,
+ * without a host wait between them. */
 typedef struct mij_secondary_params {
   uint32_t struct_size;   /* = sizeof(mij_secondary_params) */
   int quality2;           /* 1..100; 0 = the first layer's */

@@ -1131,7 +1131,11 @@ int mij_secondary_encode_host_ex(mij_encoder *e, const mij_secondary_params *sp,
       if (css2 != e->p.css) p2.restart_interval = MIJ_RESTART_AUTO;      // another MCU size: the interval that suits it
       p2.strip_mcu_row0 = p2.strip_mcu_rows = 0;
       int rc2 = mij_encoder_create(&p2, &e->sec_enc);
-      if (rc2) return fail(e, rc2, "cannot create the second layer's encoder (quality2 / css2)");
+      if (rc2) {       // keep the reason mij_encoder_create recorded (out of memory: the second handle holds workspaces of its own, see mi_jpeg.h)
+        const char *why = mij_last_error(nullptr);
+        const std::string msg = std::string("cannot create the second layer's encoder (quality2 / css2): ") + (why ? why : "?");
+        return fail(e, rc2, msg.c_str());
+      }
       e->sec_quality = q2; e->sec_css = css2;
     }
     e2 = e->sec_enc;
@@ -1153,8 +1157,8 @@ int mij_secondary_encode_host_ex(mij_encoder *e, const mij_secondary_params *sp,
   // R = clip(((I - D) << sh) + 128) with D = dec(J1) reconstructed from the coefficients J1 was coded from (no decode of the file)
   rc = encode_residual(e, e->d_src, pitch, plane_stride, fmt, d_res, pitch, plane_stride, s, sh);
   if (rc) return rc;
-  if (e2 != e) HIPCHK(e, hipStreamSynchronize(s));                                      // the second handle works on its own streams
-  rc = mij_encode_device(e2, d_res, pitch, plane_stride, fmt, e2 == e ? s : nullptr);     // J2 = enc(R)
+  // the second handle codes on the SAME stream, behind the difference map: no host wait between the layers
+  rc = mij_encode_device(e2, d_res, pitch, plane_stride, fmt, s);     // J2 = enc(R)
   if (rc) return e2 == e ? rc : fail(e, rc, mij_last_error(e2));
   size_t n2 = 0;
   rc = mij_retrieve_bitstream(e2, nullptr, &n2);

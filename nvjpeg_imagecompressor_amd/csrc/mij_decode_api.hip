@@ -387,6 +387,7 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
   const DecTables *d_final = d->d_tab;
   DcFix dc_fix{};                          // set by the parallel route: the IDCT completes the DC terms
   if (ps.fast) {
+    d->px_scans.clear();                // mij_decode_px_report speaks of THIS decode: no progressive scans in it
     DHIP(d, hipMemcpyAsync(d->d_tab, &ps.t, sizeof(DecTables), hipMemcpyHostToDevice, s));
     DHIP(d, hipStreamSynchronize(s));   // `ps` lives on this stack frame
     static const bool lanes_only = getenv("MIJ_DECODE_LANES") != nullptr;   // A/B switch: one lane per restart interval (k_huff_decode)
@@ -457,7 +458,36 @@ int mij_decode_device(mij_decoder *d, const uint8_t *jpeg, size_t jpeg_bytes, vo
         px_bytes += (px_workspace_bytes(sc.sd, g, sc.len) + 511) & ~(size_t)255;
       }
     }
-    if (px_bytes && ((rc = ensure(d, d->d_px_ws, d->px_ws_cap, px_bytes)) || (rc = ensure(d, d->d_px_flags, d->px_flags_cap, 4 * PX_FLAG_WORDS * ps.scans.size())))) return rc;
+    // The parallel decoder's workspace is sized by the FILE (hypothesis lists: 16 bytes x 2 x at least 8 M per AC refinement scan, ~2.5 GB for a
+    // luma refinement of 8320x40000), held by the handle, four scans' worth at a time. It must never be the reason a decode fails: above a
+    // byte budget (MIJ_PX_WS_BUDGET_MB, default 24,576 = 24 GiB of the 288) or when the allocation is refused, the largest scans give theirs up
+    // and are walked by the wave decoder (exact, needs none of it, slower), until the rest fits.
+    {
+      static const size_t budget = []() { const char *e = getenv("MIJ_PX_WS_BUDGET_MB"); const long long mb = e ? atoll(e) : 24576; return (size_t)(mb < 0 ? 0 : mb) << 20; }();
+      auto recount = [&]() {
+        px_bytes = 0;
+        for (size_t i = 0; i < ps.scans.size(); i++)
+          if (o_px[i] != (size_t)-1) { o_px[i] = px_bytes; px_bytes += (px_workspace_bytes(ps.scans[i].sd, g, ps.scans[i].len) + 511) & ~(size_t)255; }
+      };
+      auto drop_largest = [&]() -> bool {
+        size_t big = (size_t)-1, big_bytes = 0;
+        for (size_t i = 0; i < ps.scans.size(); i++)
+          if (o_px[i] != (size_t)-1) { const size_t b = px_workspace_bytes(ps.scans[i].sd, g, ps.scans[i].len); if (b >= big_bytes) { big = i; big_bytes = b; } }
+        if (big == (size_t)-1) return false;
+        o_px[big] = (size_t)-1;
+        recount();
+        return true;
+      };
+      while (px_bytes > budget && drop_largest()) {}
+      while (px_bytes) {
+        if (px_bytes <= d->px_ws_cap) break;
+        (void)hipFree(d->d_px_ws); d->d_px_ws = nullptr; d->px_ws_cap = 0;
+        if (hipMalloc(&d->d_px_ws, px_bytes) == hipSuccess) { d->px_ws_cap = px_bytes; break; }
+        (void)hipGetLastError();          // refused: not an error of this decode
+        if (!drop_largest()) break;
+      }
+      if (px_bytes && (rc = ensure(d, d->d_px_flags, d->px_flags_cap, 4 * PX_FLAG_WORDS * ps.scans.size()))) return rc;
+    }
     DHIP(d, hipEventRecord(d->ev_ready, s));
     for (auto &q : d->aux) DHIP(d, hipStreamWaitEvent(q, d->ev_ready, 0));
     for (size_t i = 0; i < ps.scans.size(); i++) {

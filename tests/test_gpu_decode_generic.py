@@ -173,9 +173,65 @@ with mij.Decoder() as dec:
         print("report", dec.px_report())
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env, want in (({"MIJ_PROG_PARALLEL": "0"}, "report (0, 0)"), ({"MIJ_PX_LANE_REFINE": "1"}, "report (9, 9)"), ({}, "report (9, 9)")):
+    # MIJ_PX_WS_BUDGET_MB (round 5): the parallel decoder's workspace above the budget -> those scans are walked by the wave decoder
+    # instead of the decode failing (0: none of it may be used; 1: this file's ~9 MB per refinement scan does not fit, the first scans' do)
+    for env, want in (({"MIJ_PROG_PARALLEL": "0"}, "report (0, 0)"), ({"MIJ_PX_LANE_REFINE": "1"}, "report (9, 9)"), ({}, "report (9, 9)"),
+                      ({"MIJ_PX_WS_BUDGET_MB": "0"}, "report (0, 0)"), ({"MIJ_PX_WS_BUDGET_MB": "1"}, "report (")):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout and want in r.stdout, (env, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_px_report_speaks_of_the_last_decode(mij, oracle):
+    """A progressive decode followed by a baseline decode on the same handle: the report is the baseline file's (no progressive scans)."""
+    img = oracle.synth_rgb(640, 480)
+    with mij.Decoder() as dec:
+        jp = _save(img, quality=95, subsampling=1, progressive=True, optimize=True)
+        assert np.array_equal(dec.decode_host(jp, "rgb"), _pil_dec(jp))
+        assert dec.px_report()[0] > 0
+        jb = _save(img, quality=95, subsampling=1)
+        assert np.array_equal(dec.decode_host(jb, "rgb"), _pil_dec(jb))
+        assert dec.px_report() == (0, 0)
+
+
+def test_corrupt_progressive_file_same_answer_on_both_routes():
+    """A progressive file without restart markers whose first scans carry invalid codes: the parallel decoder's exact write pass sends the
+    scan to the wave decoder, which reports it -- the return code does not depend on which route a scan took (MIJ_PROG_PARALLEL=0 / 1)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import io, sys, numpy as np
+from PIL import Image, ImageFile
+ImageFile.MAXBLOCK = 1 << 26
+sys.path.insert(0, %r)
+import nvjpeg_imagecompressor_amd as mij
+from oracle import oracle as O
+img = O.synth_rgb(800, 600)
+b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", progressive=True, optimize=False, quality=90, subsampling=1); j = bytearray(b.getvalue())
+# find the first SOS (DC scan) and the luma AC first scan (second SOS with one component); overwrite a stretch in the middle of each
+# with 0xFE bytes: sixteen 1-bits in a row is no code of a standard table (and no marker)
+out = []
+pos = [i for i in range(len(j) - 1) if j[i] == 0xFF and j[i + 1] == 0xDA]
+for which in (0, 1):
+    k = bytearray(j)
+    a, e = pos[which], pos[which + 1]
+    mid = (a + e) // 2
+    k[mid:mid + 64] = b"\xfe" * 64
+    with mij.Decoder() as dec:
+        try:
+            dec.decode_host(bytes(k), "rgb")
+            out.append("ok")
+        except mij.MiJpegError as ex:
+            out.append("err")
+print("result", out)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MIJ_PROG_PARALLEL=v), timeout=600)
+        assert r.returncode == 0 and "result" in r.stdout, (v, r.stdout[-500:], r.stderr[-2000:])
+        got[v] = r.stdout[r.stdout.index("result"):].strip()
+    assert got["0"] == got["1"], got
+    assert "err" in got["0"], got           # sixteen 1-bits is an invalid code: at least one of the two files must be refused
 
 
 def test_fullsize_progressive_file_without_restart_markers(mij):

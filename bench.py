@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--css", default=CSS_NAME)
     ap.add_argument("--quality", type=int, default=QUALITY)
     ap.add_argument("--no-optimize", action="store_true")
-    ap.add_argument("--progressive", action="store_true", help="SOF2 output (the reference's nvJPEG setting); 1 GPU only, not the headline config")
+    ap.add_argument("--progressive", action="store_true", help="SOF2 output (the reference's nvJPEG setting, ImageCompressorImpl.cu:28); not the headline config. "
+                    "N > 1: strips with a restart interval that divides the MCU row, one image at a time (sharded.encode_step_progressive)")
     ap.add_argument("--fmt", default="bgr", choices=["bgr", "rgb"])
     ap.add_argument("--restart-interval", type=int, default=-1, help="DRI in MCUs; -1 = the library's automatic choice (the headline config)")
     ap.add_argument("--loop", default=None, choices=["overlap", "tables-ahead", "one-stream", "two-streams"],
@@ -908,7 +909,10 @@ def worker_ranks(args):
     W, H = args.width, args.height
 
     # ---- strip partition (pure arithmetic, no communication) + this rank's pixels --------------------------------
-    whole_geo, r0_, r1_ = sharded.strip_rows(W, H, args.quality, optimize, args.css, rank, world, args.restart_interval)
+    ri_arg = args.restart_interval
+    if args.progressive and ri_arg < 0:       # sharded progressive: the interval must divide the MCU row (sharded.progressive_strip_interval)
+        ri_arg = sharded.progressive_strip_interval(sharded.strip_rows(W, H, args.quality, optimize, args.css, 0, 1, -1)[0]["mcus_per_row"])
+    whole_geo, r0_, r1_ = sharded.strip_rows(W, H, args.quality, optimize, args.css, rank, world, ri_arg)
     want_put = args.gather == "put" and os.environ.get("MIJ_BENCH_NO_PIPELINE") != "1" and not args.progressive
     n_handles = 1 if args.progressive or os.environ.get("MIJ_BENCH_NO_PIPELINE") == "1" else (sharded.DEPTH if want_put else 2)
     encs = [sharded.make_hip_strip_encoder(torch, W, H, args.quality, optimize, args.css, rank, world, dev_index, args.fmt,
@@ -921,9 +925,19 @@ def worker_ranks(args):
     if enc is not None:
         d_img = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
         mij.synth_image_device(d_img.data_ptr(), W, y0, rows, W * 3, bgr=(args.fmt == "bgr"), stream=stream)
-        strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=True) for e in encs]
+        if args.progressive:
+            strips = [sharded.HipProgressiveStrip(torch, e, d_img, args.fmt) for e in encs]
+        else:
+            strips = [sharded.HipStripEncoder(torch, e, d_img, args.fmt, shared_statistics=True) for e in encs]
     strip = strips[0]
     torch.cuda.synchronize()
+
+    def one_image():
+        """One image at a time, host-synchronised (the serial gather; the only form progressive output has)."""
+        st = torch.cuda.current_stream().cuda_stream
+        if args.progressive:
+            return sharded.encode_step_progressive(torch, dist, strip, cache, st)
+        return sharded.encode_step(torch, dist, strip, optimize, cache, st)
 
     copy_gbs, copy_lib_gbs = hbm_copy_ceiling(torch, mij, dev) if rank == 0 else (None, None)
     cache, stage_acc = {"device": dev}, {}
@@ -969,8 +983,8 @@ def worker_ranks(args):
 
     def step(record):
         if not pipelined:
-            out = sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
-            if record:
+            out = one_image()
+            if record and not args.progressive:
                 record_times(enc)
             return out
         if dpipe is not None:
@@ -1059,7 +1073,7 @@ def worker_ranks(args):
             pipe.step()
             pipe.flush()
         else:
-            sharded.encode_step(torch, dist, strip, optimize, cache, torch.cuda.current_stream().cuda_stream)
+            one_image()
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
     tl = torch.tensor(lat, dtype=torch.float64, device=dev)
@@ -1104,13 +1118,28 @@ def worker_ranks(args):
             print("stage-time pass failed: %r" % (ex,), file=sys.stderr)
             stage_acc.clear()
         fence()
+    # so that a first multi-GPU run explains itself: every rank's stage table (the slowest one's is quoted) and what the root takes in per image
+    mine = {k: v / steps_timed for k, v in stage_acc.items()}
+    every_stage = [None] * world
+    dist.all_gather_object(every_stage, {"rank": rank, "strip_rows": rows, "stage_ms": {k: round(v, 4) for k, v in mine.items()}})
+    inbound = None
+    if dpipe is not None:
+        sz = [int(x) for x in dpipe.sizes[0].tolist()]              # strip bytes of the last image assembled in slot 0, all ranks (device-side all-gather)
+        root0 = dpipe.roots[0]
+        inbound = {"root": root0, "strip_bytes_per_rank": sz, "inbound_bytes_per_image": int(sum(sz) - sz[root0]),
+                   "note": "what the other ranks put into the root's peer-mapped buffer for one image (the root's own strip is placed locally); the root "
+                           "rotates over the ranks, so per GPU and image on average 1/%d of this arrives" % max(1, dpipe.nroots)}
     rc = 0
     if rank == 0:
         ctx = dict(world=world, rank=rank, W=W, H=H, optimize=optimize, geo=geo, rows=rows, value=value, ms_per_step=ms_per_step, jpeg_t=jpeg_keep,
                    stages={k: v / steps_timed for k, v in stage_acc.items()}, n_handles=n_handles, gather_mode=gather_mode, dpipe=dpipe,
                    copy_gbs=copy_gbs, copy_lib_gbs=copy_lib_gbs, d_img=None, root_files=root_files, want_put=want_put, one_device=one_device,
                    rccl_ranks=rccl_ranks, single_ms=single_ms, put_rate=put_rate, streams=n_handles if dpipe is not None else 1, pipeline=None)
-        rc = report(args, torch, mij, ctx, {})
+        with_t = [e for e in every_stage if e and e["stage_ms"].get("total", 0) > 0]
+        slow = max(with_t, key=lambda e: e["stage_ms"]["total"]) if with_t else None
+        extra_n = {"slowest_rank": slow, "per_rank_total_ms": {str(e["rank"]): e["stage_ms"].get("total") for e in every_stage if e},
+                   "root_inbound": inbound}
+        rc = report(args, torch, mij, ctx, extra_n)
     for e in encs:
         if e is not None:
             e.close()

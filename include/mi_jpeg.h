@@ -327,6 +327,39 @@ MIJ_API int mij_residual_gain_device(const void *d_a, const void *d_b, void *d_o
 MIJ_API int mij_encode_residual_gain_device(mij_encoder *enc, const void *d_src, size_t pitch, size_t plane_stride, int input_format,
                                             void *d_dst, size_t dst_pitch, size_t dst_plane_stride, int gain, void *stream);
 
+/* Progressive output in STRIPS (round 5): the reference's own encoding (ImageCompressorImpl.cu:28) sharded like the baseline path.
+ * A progressive encoder may be created for a strip of MCU rows when the restart interval divides the MCUs per row and the width is a
+ * whole number of MCUs: a strip is then a whole number of restart intervals in every one of the ten scans, and the only image-wide
+ * quantity is each scan's symbol statistics. Per image, on every rank:
+ *   mij_encode_transform(enc, ...);
+ *   mij_encode_prog_statistics(enc, stream);             the ten scans' counts -> one device buffer (asynchronous on `stream`)
+ *   [caller: all-reduce (sum) of mij_prog_histogram_buffer over the ranks, on `stream`]
+ *   mij_encode_prog_emit(enc, stream, sizes, header_bytes);   tables from the image-wide counts, this strip's restart intervals coded;
+ *                                                         waits; sizes[i] = bytes of the strip's segment of scan i (every interval with
+ *                                                         its RSTn; the last strip's segments end without one), header_bytes[i] = bytes in
+ *                                                         front of scan i's data in the file (SOI .. SOS for i = 0, else DHT + SOS):
+ *                                                         identical on every rank
+ *   [caller: all-gather of sizes; offset of (scan i, rank r) = sum_{j <= i} header_bytes[j] + sum_{j < i, all r'} sizes[r'][j]
+ *                                                              + sum_{r' < r} sizes[r'][i];  file_bytes = the last such end + 2]
+ *   mij_encode_prog_place(enc, offsets, d_file, capacity, file_bytes, flags, stream);
+ *                                                         this strip's ten segments to d_file + offsets[i] (device memory of this process:
+ *                                                         the assembling rank's file buffer, or a staging buffer the caller then sends from;
+ *                                                         NULL = the handle's own buffer, grown as needed, after which mij_encode_result /
+ *                                                         mij_retrieve_bitstream return the file). Up to 2 bytes behind a segment may be
+ *                                                         overwritten (the last interval's dropped marker): leave that gap when staging.
+ *                                                         flags: MIJ_PROG_PLACE_HEADERS = also write the ten headers in front of offsets[i]
+ *                                                         (the rank of the FIRST strip, whose offsets are those of rank 0),
+ *                                                         MIJ_PROG_PLACE_EOI = also write the EOI at file_bytes - 2. Waits for its copies.
+ * One rank with the whole image gets, through these calls, the file mij_encode_entropy writes. */
+#define MIJ_PROG_SCANS 10
+#define MIJ_PROG_PLACE_HEADERS 1
+#define MIJ_PROG_PLACE_EOI 2
+MIJ_API int mij_encode_prog_statistics(mij_encoder *enc, void *stream);
+MIJ_API int mij_prog_histogram_buffer(mij_encoder *enc, void **d_ptr, size_t *words);      /* uint32 words, 10 x 4 x 257 */
+MIJ_API int mij_encode_prog_emit(mij_encoder *enc, void *stream, uint64_t sizes[MIJ_PROG_SCANS], uint64_t header_bytes[MIJ_PROG_SCANS]);
+MIJ_API int mij_encode_prog_place(mij_encoder *enc, const uint64_t offsets[MIJ_PROG_SCANS], void *d_file, size_t file_capacity,
+                                  uint64_t file_bytes, int flags, void *stream);
+
 /* Bench utility: fill device memory with rows [y0, y0+rows) of the SURVEY.md 8(d) synthetic image
  * (RGB or BGR interleaved). */
 /* Bench utility: the streaming-copy yardstick (16 B per lane, 4 loads in flight): read + write `bytes` each; all three

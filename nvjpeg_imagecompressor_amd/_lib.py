@@ -28,6 +28,7 @@ EXPORTS = (
     "mij_geometry_query", "mij_encode_entropy_sizes", "mij_encode_place", "mij_sharded_result", "mij_encoder_reserve_output",
     "mij_output_buffer", "mij_ipc_export", "mij_ipc_open", "mij_ipc_close", "mij_place_times", "mij_encode_residual_device",
     "mij_clock_probe_device", "mij_secondary_encode_host_ex", "mij_secondary_decode_host_ex", "mij_encode_residual_gain_device", "mij_residual_gain_device", "mij_output_is_uncached", "mij_decode_px_report",
+    "mij_encode_prog_statistics", "mij_prog_histogram_buffer", "mij_encode_prog_emit", "mij_encode_prog_place",
 )
 
 
@@ -158,6 +159,10 @@ def load():
     L.mij_decode_host.argtypes = [vp, vp, sz, vp, sz, C.c_int, ip, ip]
     L.mij_residual_device.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.mij_geometry_query.argtypes = [C.POINTER(EncoderParams), C.POINTER(Geometry)]
+    L.mij_encode_prog_statistics.argtypes = [vp, vp]
+    L.mij_prog_histogram_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.mij_encode_prog_emit.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mij_encode_prog_place.argtypes = [vp, C.POINTER(C.c_uint64), vp, sz, C.c_uint64, C.c_int, vp]
     L.mij_encode_entropy_sizes.argtypes = [vp, vp, vp]
     L.mij_encode_place.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, vp]
     L.mij_sharded_result.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]

@@ -31,6 +31,7 @@ struct mij_encoder {
     ScanDesc sd{};
     int Ah = 0;
     long long nseg = 0;
+    long long seg0 = 0;               // strips: index, in the whole image's scan, of the strip's first restart interval (RSTn numbering)
     size_t slot = 0;
     uint8_t *scratch = nullptr;
     uint32_t *seg_bytes = nullptr, *seg_ff = nullptr, *hist = nullptr, *ovf = nullptr;
@@ -44,6 +45,8 @@ struct mij_encoder {
     DeviceResult *res = nullptr;
   } ps[10];
   uint8_t *d_prog = nullptr;          // one allocation behind all of the above
+  uint32_t *d_prog_hist = nullptr;    // the ten scans' statistics, contiguous (10 x 4 x 257 words): what a sharded encode all-reduces in one collective
+  bool prog_stats_done = false, prog_emitted = false;   // strip protocol: mij_encode_prog_statistics / _emit issued for the current image
   hipStream_t prog_stream[4]{};
   hipEvent_t prog_ev[5]{};
   bool prog_streams = false;
@@ -253,7 +256,13 @@ static int derive_geometry(const mij_encoder_params *p_in, mij_encoder_params &p
   if (!g.last_strip && (g.mcu_count % ri)) return fail(nullptr, MIJ_ERR_INVALID_ARG, "strip does not end on a restart-interval boundary");
   g.y_origin = row0 * 8 * vs;
   geom_finish(g);
-  if (p->progressive && (row0 != 0 || rows != g.mcuy)) return fail(nullptr, MIJ_ERR_INVALID_ARG, "progressive output is for whole images (no strips)");
+  if (p->progressive && (row0 != 0 || rows != g.mcuy)) {
+    // Progressive output in strips (round 5): a scan of ONE component counts its restart intervals in blocks of that component, in raster
+    // order over the component -- so a strip of MCU rows is a whole number of intervals in every scan only if the interval divides the
+    // blocks per block row of luma (mcux * hs), of chroma and the MCUs per row (mcux): ri | mcux, and the width a whole number of MCUs.
+    if (g.wib0 != g.mcux * hs || (g.mcux % ri) != 0)
+      return fail(nullptr, MIJ_ERR_INVALID_ARG, "progressive output in strips needs a width of whole MCUs and a restart interval that divides the MCUs per row");
+  }
   return MIJ_OK;
 }
 
@@ -333,26 +342,35 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
       sd.Ss = script[i][2]; sd.Se = script[i][3]; q.Ah = script[i][4]; sd.Al = script[i][5];
       sd.kind = sd.Ss == 0 ? (q.Ah == 0 ? 1 : 2) : (q.Ah == 0 ? 3 : 4);
       sd.ri = ri;
-      if (sd.ncomp > 1) { sd.bw = g.mcux; sd.bh = g.mcuy; q.slot = e->slot_bytes; }
+      // (a strip: the scan's block rows that lie in the strip's MCU rows; the coefficient buffer and every index below are the strip's)
+      const int srow0 = (int)(g.mcu_first / g.mcux), srows = (int)(g.mcu_count / g.mcux);
+      if (sd.ncomp > 1) { sd.bw = g.mcux; sd.bh = srows; q.slot = e->slot_bytes; q.seg0 = g.mcu_first / ri; }
       else {
         const int c = sd.comp[0];
         const int cw = c == 0 ? g.W : (g.W + hs - 1) / hs, ch = c == 0 ? g.H : (g.H + vs - 1) / vs;
-        sd.bw = (cw + 7) / 8; sd.bh = (ch + 7) / 8;
+        const int per = c == 0 ? vs : 1;                     // block rows of this component per MCU row
+        const int bh_all = (ch + 7) / 8;
+        sd.bw = (cw + 7) / 8;
+        sd.bh = std::max(0, std::min(bh_all, (srow0 + srows) * per) - srow0 * per);
+        q.seg0 = ((long long)srow0 * per * sd.bw) / ri;
         q.slot = (((size_t)ri * MAX_BLOCK_BYTES + 8) + 255) & ~(size_t)255;
       }
       sd.nmcu = (long long)sd.bw * sd.bh;
       q.nseg = (sd.nmcu + ri - 1) / ri;
       const size_t nch = (size_t)((q.nseg + 1023) / 1024);
       o_scr[i] = take(q.slot * (size_t)q.nseg); o_sb[i] = take((size_t)q.nseg * 4); o_sf[i] = take((size_t)q.nseg * 4);
-      o_so[i] = take((size_t)q.nseg * 8); o_ct[i] = take(nch * 8); o_cb[i] = take(nch * 8); o_h[i] = take(4 * 257 * 4);
+      o_so[i] = take((size_t)q.nseg * 8); o_ct[i] = take(nch * 8); o_cb[i] = take(nch * 8); o_h[i] = 0;
       o_t[i] = take(sizeof(DeviceTables)); o_r[i] = take(sizeof(DeviceResult)); o_v[i] = take(4); o_f[i] = take((size_t)q.nseg);
       q.fast = prog2_supported(sd) && getenv("MIJ_PROG_SERIAL") == nullptr;   // A/B switch: the lane-per-interval kernel only
       // first guess; the count of overflowed intervals corrects it after the first image (the last luma refinement of a
       // high-quality file has blocks of more than 512 bits: q95 synthetic, a third of its intervals)
       q.narrow = q.fast && sd.kind == 4 && (sd.comp[0] != 0 || sd.Al > 0 || p->quality <= 85) && getenv("MIJ_PROG_WIDE") == nullptr;
     }
+    const size_t o_hist = take(10 * 4 * 257 * 4);            // contiguous: one collective reduces all ten over the ranks
     CRCHK(hipMalloc(&e->d_prog, total));
+    e->d_prog_hist = (uint32_t *)(e->d_prog + o_hist);
     for (int i = 0; i < 10; i++) {
+      o_h[i] = o_hist + (size_t)i * 4 * 257 * 4;
       mij_encoder::ProgScan &q = e->ps[i];
       q.scratch = e->d_prog + o_scr[i]; q.seg_bytes = (uint32_t *)(e->d_prog + o_sb[i]); q.seg_ff = (uint32_t *)(e->d_prog + o_sf[i]);
       q.seg_off = (unsigned long long *)(e->d_prog + o_so[i]); q.chunk_total = (unsigned long long *)(e->d_prog + o_ct[i]);
@@ -508,15 +526,11 @@ static int run_tail(mij_encoder *e, hipStream_t s, bool tables) {
 // workspace: gather statistics -> K3 builds the table(s) -> emit -> K5 sizes; one synchronisation brings the tables and
 // sizes to the host, which writes DHT + SOS for every scan at its final offset and launches the ten compactions (K6)
 // concurrently. Returns with the file complete.
-static int encode_progressive(mij_encoder *e, hipStream_t s) {
-  const Geom &g = e->g;
-  static const uint32_t one = 1;
-  HIPCHK(e, hipEventRecord(e->prog_ev[4], s));            // the coefficients (K1 on `s`) are ready
-  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
-  // The ten scans only READ the coefficients, so any of them may run beside any other. They go to the four streams longest
-  // first, each to the stream with the least work queued (cost ~ blocks x band width, refinement scans twice that: the two Y
-  // refinement scans are a third of all the work and must not share a stream, which the file order i & 3 made them do).
-  int order[10], owner[10];
+// ---- progressive output: pieces shared by the whole-image path (encode_progressive) and the strip protocol below -----------
+// The ten scans only READ the coefficients, so any of them may run beside any other. They go to the streams longest first, each to
+// the stream with the least work queued (cost ~ blocks x band width, refinement scans twice that: the two Y refinement scans are a
+// third of all the work and must not share a stream, which the file order i & 3 made them do).
+static void prog_plan(mij_encoder *e, int (&order)[10], int (&owner)[10]) {
   double cost[10], load[4] = {0, 0, 0, 0};
   for (int i = 0; i < 10; i++) {
     const ScanDesc &sd = e->ps[i].sd;
@@ -526,86 +540,124 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
   static const int nstreams = getenv("MIJ_PROG_STREAMS") ? std::min(4, std::max(1, atoi(getenv("MIJ_PROG_STREAMS")))) : 3;   // experiment knobs; measured at the full size:
   // 1 stream 7.06 ms, 2: 6.16, 3: 5.87, 4: 6.56 (longest first) / 6.40, 6.04, 6.00 (file order): the scan kernels nearly fill the chip alone
   static const int lpt = getenv("MIJ_PROG_ORDER") ? atoi(getenv("MIJ_PROG_ORDER")) : 1;
-  if (lpt) std::sort(order, order + 10, [&](int a, int b) { return cost[a] > cost[b]; });
+  if (lpt) std::sort(order, order + 10, [&](int x, int y) { return cost[x] > cost[y]; });
   for (int k = 0; k < 10; k++) {
     int best = 0;
     for (int q4 = 1; q4 < nstreams; q4++) if (load[q4] < load[best]) best = q4;
     if (!lpt) best = order[k] % nstreams;
     owner[order[k]] = best; load[best] += cost[order[k]];
   }
-  for (int k = 0; k < 10; k++) {
-    const int i = order[k];
-    mij_encoder::ProgScan &q = e->ps[i];
-    hipStream_t st = e->prog_stream[owner[i]];
-    q.stream_index = owner[i];
-    if (q.sd.kind != 2) {
-      HIPCHK(e, hipMemsetAsync(q.hist, 0, 4 * 257 * sizeof(uint32_t), st));
-      // (K3 builds all four tables; the ones this scan does not use get a single count so that they are well formed:
-      //  the lane-per-block gather kernels write it themselves, the serial one gets it by copy)
-      if (q.fast) HIPCHK(e, launch_prog2(g, q.sd, 1, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st, false, nullptr));
-      else {
-        HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
-        for (int w = 0; w < 4; w++) {
-          const bool used = q.sd.kind == 1 ? (w == 0 || w == 2) : (w == (q.sd.comp[0] ? 3 : 1));
-          if (!used) HIPCHK(e, hipMemcpyAsync(q.hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, st));
-        }
-      }
-      // (K3 also writes a baseline header into the first HDR_AREA bytes of d_out; the progressive file starts after them)
-      HIPCHK(e, launch_build_tables(g, q.hist, 1, e->d_qt, q.tab, e->d_out, q.res, st));
-      HIPCHK(e, hipMemcpyAsync(&e->h_prog_tab[i], q.tab, sizeof(DeviceTables), hipMemcpyDeviceToHost, st));
+}
+// statistics of scan i into its slice of d_prog_hist (DC refinement scans have none)
+static int prog_gather(mij_encoder *e, int i, hipStream_t st) {
+  static const uint32_t one = 1;
+  const Geom &g = e->g;
+  mij_encoder::ProgScan &q = e->ps[i];
+  if (q.sd.kind == 2) return MIJ_OK;
+  HIPCHK(e, hipMemsetAsync(q.hist, 0, 4 * 257 * sizeof(uint32_t), st));
+  // (K3 builds all four tables; the ones this scan does not use get a single count so that they are well formed:
+  //  the lane-per-block gather kernels write it themselves, the serial one gets it by copy)
+  if (q.fast) HIPCHK(e, launch_prog2(g, q.sd, 1, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st, false, nullptr));
+  else {
+    HIPCHK(e, launch_prog_encode(g, q.sd, 1, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+    for (int w = 0; w < 4; w++) {
+      const bool used = q.sd.kind == 1 ? (w == 0 || w == 2) : (w == (q.sd.comp[0] ? 3 : 1));
+      if (!used) HIPCHK(e, hipMemcpyAsync(q.hist + w * 257, &one, sizeof one, hipMemcpyHostToDevice, st));
     }
-    if (q.fast) {
-      // lane per block; intervals it hands back (forced flushes of jcphuff.c, oversized blocks) go through the serial kernel
-      HIPCHK(e, launch_prog2(g, q.sd, 0, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st, q.narrow, q.res));
-      if (q.sd.kind >= 3) HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st, q.flag));
-    } else HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
-    HIPCHK(e, launch_scan(q.seg_bytes, q.seg_ff, q.seg_off, q.nseg, q.chunk_total, q.chunk_base, q.ovf, q.res, st));
-    HIPCHK(e, hipMemcpyAsync(&e->h_prog_res[i], q.res, sizeof(DeviceResult), hipMemcpyDeviceToHost, st));
   }
-  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamSynchronize(st));
-  for (int i = 0; i < 10; i++) {        // as note_recoded for K4: more than 1 % of the intervals re-coded -> wide strips from now on
+  return MIJ_OK;
+}
+// scan i: its table(s) from the statistics (to the host as well: the DHT segment), its restart intervals' bits, their sizes
+static int prog_tables_emit(mij_encoder *e, int i, hipStream_t st) {
+  const Geom &g = e->g;
+  mij_encoder::ProgScan &q = e->ps[i];
+  if (q.sd.kind != 2) {
+    // (K3 also writes a baseline header into the first HDR_AREA bytes of d_out; the progressive file starts after them)
+    HIPCHK(e, launch_build_tables(g, q.hist, 1, e->d_qt, q.tab, e->d_out, q.res, st));
+    HIPCHK(e, hipMemcpyAsync(&e->h_prog_tab[i], q.tab, sizeof(DeviceTables), hipMemcpyDeviceToHost, st));
+  }
+  if (q.fast) {
+    // lane per block; intervals it hands back (forced flushes of jcphuff.c, oversized blocks) go through the serial kernel
+    HIPCHK(e, launch_prog2(g, q.sd, 0, e->d_coef, e->d_dc, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.flag, q.nseg, st, q.narrow, q.res));
+    if (q.sd.kind >= 3) HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st, q.flag));
+  } else HIPCHK(e, launch_prog_encode(g, q.sd, 0, e->d_coef, q.tab, q.scratch, q.slot, q.seg_bytes, q.seg_ff, q.hist, q.nseg, st));
+  HIPCHK(e, launch_scan(q.seg_bytes, q.seg_ff, q.seg_off, q.nseg, q.chunk_total, q.chunk_base, q.ovf, q.res, st));
+  HIPCHK(e, hipMemcpyAsync(&e->h_prog_res[i], q.res, sizeof(DeviceResult), hipMemcpyDeviceToHost, st));
+  return MIJ_OK;
+}
+static void prog_note_recoded(mij_encoder *e) {      // as note_recoded for K4: more than 1 % of the intervals re-coded -> wide strips from now on
+  for (int i = 0; i < 10; i++) {
     mij_encoder::ProgScan &q = e->ps[i];
     const uint32_t d = e->h_prog_res[i].recoded - q.seen_recoded;
     q.seen_recoded = e->h_prog_res[i].recoded;
     if (q.narrow && (long long)d * 100 > q.nseg) q.narrow = false;
   }
-
-  // ---- headers and offsets (jcmarker.c: frame header; per scan DHT of the tables it uses, DRI before the first SOS, SOS)
-  std::vector<uint8_t> hdr[10];
+}
+// what precedes scan i's entropy-coded data in the file (jcmarker.c: frame header in front of the first scan; per scan the DHT of the
+// tables it uses, DRI before the first SOS, SOS). Depends on the image-wide statistics only: every rank of a sharded encode builds the same.
+static void prog_header(const mij_encoder *e, int i, std::vector<uint8_t> &h) {
   static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
                                  28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61,
                                  54, 47, 55, 62, 63};
+  const Geom &g = e->g;
+  const mij_encoder::ProgScan &q = e->ps[i];
+  h.clear();
+  auto put = [&](int b) { h.push_back((uint8_t)b); };
+  auto put16 = [&](int v) { put(v >> 8); put(v & 255); };
+  if (i == 0) {
+    put16(0xFFD8);
+    put16(0xFFE0); put16(16); put('J'); put('F'); put('I'); put('F'); put(0); put(1); put(1); put(0); put16(1); put16(1); put(0); put(0);
+    for (int t = 0; t < 2; t++) { put16(0xFFDB); put16(67); put(t); for (int k = 0; k < 64; k++) put(e->hq.q[t][zz[k]]); }
+    put16(0xFFC2); put16(17); put(8); put16(g.H); put16(g.W); put(3);
+    put(1); put((g.hs << 4) | g.vs); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
+  }
+  const DeviceTables &ht = e->h_prog_tab[i];
+  auto dht = [&](int w, int tcth) {
+    const int nv = (int)ht.nvals[w];
+    put16(0xFFC4); put16(19 + nv); put(tcth);
+    for (int k = 1; k <= 16; k++) put(ht.bits[w][k]);
+    for (int k = 0; k < nv; k++) put(ht.vals[w][k]);
+  };
+  if (q.sd.kind == 1) { dht(0, 0x00); dht(2, 0x01); }
+  else if (q.sd.kind >= 3) dht(q.sd.comp[0] ? 3 : 1, 0x10 | (q.sd.comp[0] ? 1 : 0));
+  if (i == 0) { put16(0xFFDD); put16(4); put16(g.ri); }
+  put16(0xFFDA); put16(6 + 2 * q.sd.ncomp); put(q.sd.ncomp);
+  for (int k = 0; k < q.sd.ncomp; k++) {
+    const int c = q.sd.comp[k], t = c ? 1 : 0;
+    put(c + 1);
+    put(q.sd.Ss == 0 ? (q.Ah == 0 ? (t << 4) : 0) : t);   // jcmarker.c emit_sos: only the table kind the scan uses
+  }
+  put(q.sd.Ss); put(q.sd.Se); put((q.Ah << 4) | q.sd.Al);
+}
+// scan i's restart intervals, stuffed, back to back at `dst` (K6; RSTn behind every one of them, numbered from the scan's first
+// interval in the WHOLE image: q.seg0 counts the intervals of the strips in front)
+static int prog_compact(mij_encoder *e, int i, uint8_t *dst, size_t room) {
+  const mij_encoder::ProgScan &q = e->ps[i];
+  Geom g2 = e->g; g2.last_strip = 0; g2.mcu_first = 0; g2.seg0 = (uint32_t)q.seg0;       // RSTn numbering restarts in every scan, never an EOI
+  HIPCHK(e, launch_compact(g2, q.scratch, q.slot, q.seg_bytes, q.seg_off, q.chunk_base, q.nseg, dst, room, q.res, e->prog_stream[q.stream_index]));
+  return MIJ_OK;
+}
+
+static int encode_progressive(mij_encoder *e, hipStream_t s) {
+  HIPCHK(e, hipEventRecord(e->prog_ev[4], s));            // the coefficients (K1 on `s`) are ready
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
+  int order[10], owner[10], rc;
+  prog_plan(e, order, owner);
+  for (int k = 0; k < 10; k++) {
+    const int i = order[k];
+    hipStream_t st = e->prog_stream[owner[i]];
+    e->ps[i].stream_index = owner[i];
+    if ((rc = prog_gather(e, i, st)) || (rc = prog_tables_emit(e, i, st))) return rc;
+  }
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamSynchronize(st));
+  prog_note_recoded(e);
+
+  // ---- headers and offsets
+  std::vector<uint8_t> hdr[10];
   size_t off = 0, data_off[10];
   for (int i = 0; i < 10; i++) {
-    const mij_encoder::ProgScan &q = e->ps[i];
-    std::vector<uint8_t> &h = hdr[i];
-    auto put = [&](int b) { h.push_back((uint8_t)b); };
-    auto put16 = [&](int v) { put(v >> 8); put(v & 255); };
-    if (i == 0) {
-      put16(0xFFD8);
-      put16(0xFFE0); put16(16); put('J'); put('F'); put('I'); put('F'); put(0); put(1); put(1); put(0); put16(1); put16(1); put(0); put(0);
-      for (int t = 0; t < 2; t++) { put16(0xFFDB); put16(67); put(t); for (int k = 0; k < 64; k++) put(e->hq.q[t][zz[k]]); }
-      put16(0xFFC2); put16(17); put(8); put16(g.H); put16(g.W); put(3);
-      put(1); put((g.hs << 4) | g.vs); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
-    }
-    const DeviceTables &ht = e->h_prog_tab[i];
-    auto dht = [&](int w, int tcth) {
-      const int nv = (int)ht.nvals[w];
-      put16(0xFFC4); put16(19 + nv); put(tcth);
-      for (int k = 1; k <= 16; k++) put(ht.bits[w][k]);
-      for (int k = 0; k < nv; k++) put(ht.vals[w][k]);
-    };
-    if (q.sd.kind == 1) { dht(0, 0x00); dht(2, 0x01); }
-    else if (q.sd.kind >= 3) dht(q.sd.comp[0] ? 3 : 1, 0x10 | (q.sd.comp[0] ? 1 : 0));
-    if (i == 0) { put16(0xFFDD); put16(4); put16(g.ri); }
-    put16(0xFFDA); put16(6 + 2 * q.sd.ncomp); put(q.sd.ncomp);
-    for (int k = 0; k < q.sd.ncomp; k++) {
-      const int c = q.sd.comp[k], t = c ? 1 : 0;
-      put(c + 1);
-      put(q.sd.Ss == 0 ? (q.Ah == 0 ? (t << 4) : 0) : t);   // jcmarker.c emit_sos: only the table kind the scan uses
-    }
-    put(q.sd.Ss); put(q.sd.Se); put((q.Ah << 4) | q.sd.Al);
-    off += h.size();
+    prog_header(e, i, hdr[i]);
+    off += hdr[i].size();
     data_off[i] = off;
     const size_t sb = (size_t)e->h_prog_res[i].scan_bytes;
     if (sb < 2) return fail(e, MIJ_ERR_OVERFLOW, "progressive scan produced no data");
@@ -621,13 +673,9 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
     e->d_out = nb; e->capacity = need;
   }
   uint8_t *const file = e->d_out + HDR_AREA;
-  Geom g2 = g; g2.last_strip = 0; g2.mcu_first = 0;       // K6: RSTn numbering restarts in every scan, never an EOI
   // compactions first (each one's trailing RSTn lands on the next scan's header position), then the headers on top
-  for (int i = 0; i < 10; i++) {
-    const mij_encoder::ProgScan &q = e->ps[i];
-    HIPCHK(e, launch_compact(g2, q.scratch, q.slot, q.seg_bytes, q.seg_off, q.chunk_base, q.nseg, file + data_off[i], e->capacity - data_off[i],
-                             q.res, e->prog_stream[q.stream_index]));
-  }
+  for (int i = 0; i < 10; i++)
+    if ((rc = prog_compact(e, i, file + data_off[i], e->capacity - data_off[i]))) return rc;
   for (int q4 = 0; q4 < 4; q4++) {
     HIPCHK(e, hipEventRecord(e->prog_ev[q4], e->prog_stream[q4]));
     HIPCHK(e, hipStreamWaitEvent(s, e->prog_ev[q4], 0));
@@ -641,6 +689,127 @@ static int encode_progressive(mij_encoder *e, hipStream_t s) {
   HIPCHK(e, hipStreamSynchronize(s));       // `hdr` lives on this stack frame
   e->h_res->scan_bytes = off; e->h_res->header_bytes = 0; e->h_res->flags = 0;
   e->issued = true;
+  return MIJ_OK;
+}
+
+// ---- progressive output in strips (round 5; SURVEY.md 8e for the reference's own encoding, ImageCompressorImpl.cu:28) ------------
+// With a restart interval that divides the MCU row every scan of libjpeg's script is strip-separable: a strip of MCU rows is a
+// whole number of restart intervals in each of the ten scans, DC prediction and end-of-band runs stop at interval boundaries, and
+// the only image-wide quantity is each scan's symbol statistics. So N ranks write the 1-rank file with ONE collective:
+//   every rank:  mij_encode_transform; mij_encode_prog_statistics            (the ten scans' counts -> one contiguous device buffer)
+//   caller:      all-reduce (sum) of mij_prog_histogram_buffer over the ranks
+//   every rank:  mij_encode_prog_emit -> sizes[10], header_bytes[10]         (tables from the image-wide counts; this strip's intervals)
+//   caller:      all-gather of sizes; file offset of (scan i, rank r) = sum of headers 0..i + sizes of scans < i + sizes[r' < r][i]
+//   every rank:  mij_encode_prog_place(offsets, d_file, ...)                  (its ten segments to their places; flags say who writes
+//                                                                             the headers -- the first strip's rank -- and the EOI)
+// One rank with the whole image gives, through the same three calls, what mij_encode_entropy gives (the tests compare them).
+int mij_encode_prog_statistics(mij_encoder *e, void *stream) {
+  if (!e) return MIJ_ERR_INVALID_ARG;
+  if (!e->p.progressive) return fail(e, MIJ_ERR_INVALID_ARG, "mij_encode_prog_statistics needs a progressive encoder");
+  if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_prog_statistics called before mij_encode_transform");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  if (s != e->last_stream) HIPCHK(e, hipStreamWaitEvent(s, e->ev_xdone, 0));
+  e->last_stream = s;
+  int order[10], owner[10], rc;
+  prog_plan(e, order, owner);
+  // (DC refinement scans gather nothing: their slices stay zero, a sum over the ranks leaves them so)
+  HIPCHK(e, hipMemsetAsync(e->d_prog_hist, 0, 10 * 4 * 257 * sizeof(uint32_t), s));
+  HIPCHK(e, hipEventRecord(e->prog_ev[4], s));
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
+  for (int k = 0; k < 10; k++) {
+    const int i = order[k];
+    e->ps[i].stream_index = owner[i];
+    if ((rc = prog_gather(e, i, e->prog_stream[owner[i]]))) return rc;
+  }
+  for (int q4 = 0; q4 < 4; q4++) {          // the caller's collective, on `s`, comes behind all of them
+    HIPCHK(e, hipEventRecord(e->prog_ev[q4], e->prog_stream[q4]));
+    HIPCHK(e, hipStreamWaitEvent(s, e->prog_ev[q4], 0));
+  }
+  e->prog_stats_done = true; e->prog_emitted = false;
+  return MIJ_OK;
+}
+
+int mij_prog_histogram_buffer(mij_encoder *e, void **d_ptr, size_t *words) {
+  if (!e || !d_ptr || !words) return MIJ_ERR_INVALID_ARG;
+  if (!e->p.progressive || !e->d_prog_hist) return fail(e, MIJ_ERR_INVALID_ARG, "not a progressive encoder");
+  *d_ptr = e->d_prog_hist; *words = 10 * 4 * 257;
+  return MIJ_OK;
+}
+
+int mij_encode_prog_emit(mij_encoder *e, void *stream, uint64_t sizes[10], uint64_t header_bytes[10]) {
+  if (!e || !sizes || !header_bytes) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  if (!e->p.progressive || !e->prog_stats_done) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_prog_emit follows mij_encode_prog_statistics");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  e->last_stream = s;
+  HIPCHK(e, hipEventRecord(e->prog_ev[4], s));            // behind the caller's all-reduce of the statistics
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamWaitEvent(st, e->prog_ev[4], 0));
+  int rc;
+  for (int i = 0; i < 10; i++)
+    if ((rc = prog_tables_emit(e, i, e->prog_stream[e->ps[i].stream_index]))) return rc;
+  for (auto &st : e->prog_stream) HIPCHK(e, hipStreamSynchronize(st));
+  prog_note_recoded(e);
+  std::vector<uint8_t> h;
+  for (int i = 0; i < 10; i++) {
+    prog_header(e, i, h);
+    header_bytes[i] = h.size();
+    const size_t sb = (size_t)e->h_prog_res[i].scan_bytes;
+    if (e->ps[i].nseg > 0 && sb < 2) return fail(e, MIJ_ERR_OVERFLOW, "progressive scan produced no data");
+    // every interval ends with its RSTn (K6); the file's last interval of a scan has none: the last strip's segment is 2 bytes shorter
+    sizes[i] = e->g.last_strip ? sb - 2 : sb;
+  }
+  e->prog_stats_done = false; e->prog_emitted = true;
+  return MIJ_OK;
+}
+
+int mij_encode_prog_place(mij_encoder *e, const uint64_t offsets[10], void *d_file, size_t file_capacity, uint64_t file_bytes, int flags,
+                          void *stream) {
+  if (!e || !offsets) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
+  if (!e->p.progressive || !e->prog_emitted) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_prog_place follows mij_encode_prog_emit");
+  HIPCHK(e, hipSetDevice(e->p.device));
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t *file = (uint8_t *)d_file;
+  size_t cap = file_capacity;
+  if (!file) {           // this handle's own buffer (one rank, or a root that assembles at home): make room first, all sizes are known
+    if (file_bytes + 4 > e->capacity) {
+      const size_t need = (size_t)file_bytes + 65536;
+      uint8_t *nb = nullptr;
+      if (hipMalloc(&nb, HDR_AREA + need + 64) != hipSuccess) return fail(e, MIJ_ERR_OVERFLOW, "cannot grow the output buffer");
+      (void)hipFree(e->d_out);
+      e->d_out = nb; e->capacity = need;
+    }
+    file = e->d_out + HDR_AREA; cap = e->capacity;
+  }
+  std::vector<uint8_t> hdr[10];
+  int rc;
+  for (int i = 0; i < 10; i++) {
+    const size_t sb = (size_t)e->h_prog_res[i].scan_bytes;
+    if (offsets[i] + sb > cap) return fail(e, MIJ_ERR_OVERFLOW, "a scan's segment does not fit the target at its offset");
+    if (flags & MIJ_PROG_PLACE_HEADERS) {
+      prog_header(e, i, hdr[i]);
+      if (hdr[i].size() > offsets[i]) return fail(e, MIJ_ERR_INVALID_ARG, "offset of a scan's first segment leaves no room for its header");
+    }
+  }
+  // compactions first (each one's trailing RSTn may land on what follows: the next scan's header, the next rank's segment is NOT touched --
+  // only the file's last interval of a scan loses its marker, and that one is followed by a header or the EOI), then the headers on top
+  for (int i = 0; i < 10; i++)
+    if (e->ps[i].nseg > 0 && (rc = prog_compact(e, i, file + offsets[i], cap - (size_t)offsets[i]))) return rc;
+  for (int q4 = 0; q4 < 4; q4++) {
+    HIPCHK(e, hipEventRecord(e->prog_ev[q4], e->prog_stream[q4]));
+    HIPCHK(e, hipStreamWaitEvent(s, e->prog_ev[q4], 0));
+  }
+  if (flags & MIJ_PROG_PLACE_HEADERS)
+    for (int i = 0; i < 10; i++)
+      HIPCHK(e, hipMemcpyAsync(file + offsets[i] - hdr[i].size(), hdr[i].data(), hdr[i].size(), hipMemcpyHostToDevice, s));
+  if (flags & MIJ_PROG_PLACE_EOI) {
+    if (file_bytes < 2 || file_bytes > cap) return fail(e, MIJ_ERR_INVALID_ARG, "file_bytes does not fit the target");
+    static const uint8_t eoi[2] = {0xFF, 0xD9};
+    HIPCHK(e, hipMemcpyAsync(file + file_bytes - 2, eoi, 2, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(e, hipStreamSynchronize(s));       // `hdr` lives on this stack frame
+  if (!d_file) { e->h_res->scan_bytes = file_bytes; e->h_res->header_bytes = 0; e->h_res->flags = 0; e->issued = true; }
+  e->prog_emitted = false;
   return MIJ_OK;
 }
 
@@ -720,7 +889,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
 int mij_encode_entropy_sizes(mij_encoder *e, uint64_t *d_size_slot, void *stream) {
   if (!e || !d_size_slot) return fail(e, MIJ_ERR_INVALID_ARG, "null argument");
   if (!e->transformed) return fail(e, MIJ_ERR_NOT_READY, "mij_encode_entropy_sizes called before mij_encode_transform");
-  if (e->p.progressive) return fail(e, MIJ_ERR_INVALID_ARG, "progressive output is not sharded");
+  if (e->p.progressive) return fail(e, MIJ_ERR_INVALID_ARG, "progressive output is sharded through mij_encode_prog_statistics / _emit / _place");
   HIPCHK(e, hipSetDevice(e->p.device));
   hipStream_t s = (hipStream_t)stream;
   e->last_stream = s;

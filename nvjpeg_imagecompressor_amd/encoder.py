@@ -93,6 +93,29 @@ class Encoder:
         _lib.check(self._L.mij_place_times(self._h, ms), self._h, "mij_place_times")
         return float(ms[0]), float(ms[1])
 
+    # -- progressive output in strips (mi_jpeg.h "Progressive output in STRIPS") ---------------------------------------
+    PROG_SCANS, PROG_PLACE_HEADERS, PROG_PLACE_EOI = 10, 1, 2
+
+    def prog_statistics(self, stream=0):
+        _lib.check(self._L.mij_encode_prog_statistics(self._h, C.c_void_p(stream)), self._h, "mij_encode_prog_statistics")
+
+    def prog_histogram_buffer(self):
+        """(device pointer, uint32 words) of the ten scans' statistics: what the ranks of a sharded encode sum in place."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self._L.mij_prog_histogram_buffer(self._h, C.byref(p), C.byref(n)), self._h, "mij_prog_histogram_buffer")
+        return p.value, n.value
+
+    def prog_emit(self, stream=0):
+        """-> (sizes[10], header_bytes[10]) on the host (waits for the ten scans)."""
+        a, b = (C.c_uint64 * 10)(), (C.c_uint64 * 10)()
+        _lib.check(self._L.mij_encode_prog_emit(self._h, C.c_void_p(stream), a, b), self._h, "mij_encode_prog_emit")
+        return [int(v) for v in a], [int(v) for v in b]
+
+    def prog_place(self, offsets, d_file=0, capacity=0, file_bytes=0, flags=0, stream=0):
+        o = (C.c_uint64 * 10)(*[int(v) for v in offsets])
+        _lib.check(self._L.mij_encode_prog_place(self._h, o, C.c_void_p(d_file or 0), capacity, file_bytes, flags, C.c_void_p(stream)), self._h,
+                   "mij_encode_prog_place")
+
     def residual_device(self, d_src, pitch, d_dst, fmt="bgr", plane_stride=0, dst_pitch=None, dst_plane_stride=None, stream=0, gain=1):
         """After encode_device / transform of image I on this handle: d_dst <- clip((I - D) * gain + 128) with D = what a decoder
         makes of this handle's file, computed from the coefficients (d_src = I); d_src = 0 / None: d_dst <- D itself."""

@@ -505,6 +505,130 @@ def _buffer(torch, cache, n, device):
     return buf
 
 
+# =====================================================================================================================
+# Progressive output, sharded (round 5): the reference's own encoding (ImageCompressorImpl.cu:28) over N ranks
+# =====================================================================================================================
+def progressive_strip_interval(mcus_per_row):
+    """Restart interval of a SHARDED progressive encode: it must divide the MCUs per row (every one of the ten scans then cuts into
+    restart intervals at strip boundaries; mi_jpeg.h). The largest divisor up to 1024 MCUs: long intervals suit the progressive coder
+    (520 at the headline width, where one rank alone picks 640)."""
+    best = 1
+    for d in range(1, min(mcus_per_row, 1024) + 1):
+        if mcus_per_row % d == 0:
+            best = d
+    return best
+
+
+def progressive_offsets(sizes, header_bytes):
+    """sizes[r][i]: bytes of rank r's segment of scan i (mij_encode_prog_emit, all-gathered); header_bytes[i]: bytes in front of scan i's
+    data. -> (offsets[r][i], file_bytes): where every segment goes in the file, scans in order, within a scan the ranks in order."""
+    world = len(sizes)
+    offs = [[0] * 10 for _ in range(world)]
+    off = 0
+    for i in range(10):
+        off += header_bytes[i]
+        for r in range(world):
+            offs[r][i] = off
+            off += sizes[r][i]
+    return offs, off + 2          # + EOI
+
+
+class HipProgressiveStrip:
+    """This rank's strip of a sharded PROGRESSIVE encode, backed by libmijpeg (HIP)."""
+
+    def __init__(self, torch, enc, d_img, fmt="bgr"):
+        self.torch, self.enc, self.d_img, self.fmt = torch, enc, d_img, fmt
+        self.pitch = d_img.stride(0) * d_img.element_size()
+        p, n = enc.prog_histogram_buffer()
+        self.hist = device_words(torch, p, n, d_img.device)        # int32 view over the handle's buffer: reduced in place
+        self.stage = None
+
+    def statistics(self, stream=0):
+        self.enc.transform(self.d_img.data_ptr(), self.pitch, self.fmt, 0, stream)
+        self.enc.prog_statistics(stream)
+        return self.hist
+
+    def emit(self, stream=0):
+        return self.enc.prog_emit(stream)
+
+    def place_into(self, file_tensor, offsets, file_bytes, flags, stream=0):
+        self.enc.prog_place(offsets, file_tensor.data_ptr(), file_tensor.numel(), file_bytes, flags, stream)
+
+    def place_staged(self, sizes, stream=0):
+        """The ten segments into a staging tensor of this rank, 64 bytes apart (a segment's dropped last marker may spill two bytes);
+        -> the ten views to send."""
+        torch = self.torch
+        local, off = [], 0
+        for n in sizes:
+            local.append(off)
+            off += n + 64
+        if self.stage is None or self.stage.numel() < off + 64:
+            self.stage = torch.empty(off + (off >> 3) + 4096, dtype=torch.uint8, device=self.d_img.device)
+        self.enc.prog_place(local, self.stage.data_ptr(), self.stage.numel(), 0, 0, stream)
+        return [self.stage[o:o + n] for o, n in zip(local, sizes)]
+
+
+def device_words(torch, ptr, nwords, device):
+    """int32 tensor view over device memory owned by libmijpeg."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(nwords),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=device)
+
+
+def encode_step_progressive(torch, dist, strip, cache, stream=0):
+    """One whole-image PROGRESSIVE encode across all ranks of the default process group, one image at a time, host-synchronised:
+    statistics -> ONE all-reduce (10 x 4 x 257 words) -> tables + this strip's intervals of all ten scans -> all-gather of the 10 sizes per rank ->
+    every rank's ten segments travel to rank 0 (point-to-point), which writes headers and EOI. Returns, on rank 0, a uint8 tensor with
+    the complete file (a view into cache["buf"]); None elsewhere. `strip` may be None on a rank that owns no strip. The strip object
+    may be any implementation of HipProgressiveStrip's four methods (the CPU tests play it with the oracle)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    dev = cache.get("device", "cpu")
+    hist = strip.statistics(stream) if strip is not None else torch.zeros(10 * 4 * 257, dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(hist)                                  # the only collective in front of the entropy stage
+    sizes, hdr = strip.emit(stream) if strip is not None else ([0] * 10, [0] * 10)
+    if world == 1:
+        offs, total = progressive_offsets([sizes], hdr)
+        buf = _buffer(torch, cache, total + 64, dev)
+        strip.place_into(buf, offs[0], total, 3, stream)       # headers + EOI
+        return buf[:total]
+    mine = torch.tensor(sizes + hdr, dtype=torch.int64, device=dev)
+    every = torch.zeros(world * 20, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(every, mine)
+    ev = every.cpu().view(world, 20).tolist()
+    all_sizes = [[int(v) for v in row[:10]] for row in ev]
+    owners = [r for r in range(world) if sum(all_sizes[r]) > 0]
+    if not owners:
+        raise RuntimeError("no rank owns a strip")
+    first = owners[0]
+    hdr = [int(v) for v in ev[first][10:]]                     # (identical on every rank that owns a strip)
+    offs, total = progressive_offsets(all_sizes, hdr)
+    if first != 0:              # (partition_mcu_rows hands the strips out from rank 0 on: the same arithmetic on every rank)
+        raise RuntimeError("rank 0 must own the first strip")
+    if rank == 0:
+        buf = _buffer(torch, cache, total + 64, dev)
+        strip.place_into(buf, offs[0], total, 3, stream)       # its own ten segments, the ten headers, the EOI
+        ops = []
+        for r in range(1, world):
+            for i in range(10):
+                if all_sizes[r][i]:
+                    ops.append(dist.P2POp(dist.irecv, buf[offs[r][i]:offs[r][i] + all_sizes[r][i]], r))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return buf[:total]
+    if strip is not None:
+        segs = strip.place_staged(sizes, stream)
+        ops = [dist.P2POp(dist.isend, sg, 0) for sg in segs if sg.numel()]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+    return None
+
+
 def strip_rows(width, height, quality, optimize, css, rank, world, restart_interval=-1):
     """(whole-image geometry, first MCU row, one-past-last MCU row) of `rank`: pure arithmetic (mij_geometry_query), no
     device and no communication. r0 == r1: this rank owns no strip."""
@@ -518,11 +642,17 @@ def make_hip_strip_encoder(torch, width, height, quality, optimize, css, rank, w
                            restart_interval=-1, progressive=False):
     """This rank's Encoder for its strip (its `geometry` tells which pixel rows to fill), or None if the rank owns no strip
     (more ranks than restart-aligned strips)."""
-    g0, r0, r1 = strip_rows(width, height, quality, optimize, css, rank, world, restart_interval)
-    if progressive:
-        if world != 1:
-            raise ValueError("progressive output is not sharded: every scan spans the whole image")
+    if progressive and world == 1:
         return Encoder(width, height, quality, optimize, css, restart_interval, device_index, progressive=True)   # (its own AUTO rule: a multiple of 64 blocks)
+    if progressive:
+        # sharded: the interval must divide the MCU row (progressive_strip_interval), strips are whole MCU rows
+        g00 = geometry_query(width, height, quality, optimize, css, restart_interval)
+        ri = restart_interval if restart_interval > 0 else progressive_strip_interval(g00["mcus_per_row"])
+        g0, r0, r1 = strip_rows(width, height, quality, optimize, css, rank, world, ri)
+        if r1 <= r0:
+            return None
+        return Encoder(width, height, quality, optimize, css, ri, device_index, r0, r1 - r0, progressive=True)
+    g0, r0, r1 = strip_rows(width, height, quality, optimize, css, rank, world, restart_interval)
     if r1 <= r0:
         return None
     return Encoder(width, height, quality, optimize, css, g0["restart_interval"], device_index, r0, r1 - r0)

@@ -19,7 +19,8 @@ CASES = [("css1_ri64_opt", 1, 64, True, False), ("css0_ri64_opt", 0, 64, True, F
          ("css3_ri64_opt", 3, 64, True, False), ("css4_ri32_opt", 4, 32, True, False), ("css1_ri64_fix", 1, 64, False, False),
          ("css1_ri104_opt", 1, 104, True, False), ("css0_ri104_opt", 0, 104, True, False), ("css2_ri52_opt", 2, 52, True, False),
          ("css3_ri80_opt", 3, 80, True, False), ("css4_ri52_opt", 4, 52, True, False), ("css1_ri104_fix", 1, 104, False, False),
-         ("css1_ri104_progressive", 1, 104, True, True), ("css1_ri640_progressive", 1, 640, True, True)]
+         ("css1_ri104_progressive", 1, 104, True, True), ("css1_ri640_progressive", 1, 640, True, True),
+         ("css1_ri520_progressive", 1, 520, True, True)]      # 520 = the MCU row: the interval of a SHARDED progressive encode (sharded.progressive_strip_interval)
 
 
 def main():

@@ -63,9 +63,15 @@ def test_progressive_smaller_than_baseline_and_same_pixels(mij, oracle):
         assert np.array_equal(dec.decode_host(prog, "rgb"), b)
 
 
-def test_progressive_rejects_strips(mij):
-    with pytest.raises(mij.MiJpegError, match="whole images"):
-        mij.Encoder(512, 512, 90, True, 0, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)
+def test_progressive_strips_need_an_aligned_interval(mij):
+    """Round 5: a progressive encoder may own a strip when every scan's restart intervals end at the strip's boundaries -- the interval
+    divides the MCUs per row and the width is a whole number of MCUs (tests/test_gpu_sharded.py encodes with such strips)."""
+    with pytest.raises(mij.MiJpegError, match="divides the MCUs per row"):
+        mij.Encoder(2080, 1000, 95, True, 1, restart_interval=64, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)     # 130 MCUs per row
+    with pytest.raises(mij.MiJpegError, match="whole MCUs"):
+        mij.Encoder(520, 512, 90, True, 1, restart_interval=33, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)       # 65 luma blocks, 33 MCUs per row
+    with mij.Encoder(512, 512, 90, True, 0, strip_mcu_row0=8, strip_mcu_rows=8, progressive=True) as e:                    # AUTO = 64 = the MCU row here
+        assert e.geometry["restart_interval"] == 64 and e.geometry["strip_y0"] == 64
 
 
 def test_facade_progressive(mij, oracle, capsys):

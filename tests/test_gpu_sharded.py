@@ -282,3 +282,68 @@ def test_bench_falls_back_to_send_recv_with_fresh_ranks(one_gpu_line, inject, ex
                     env_extra={"MIJ_BENCH_INJECT": inject, "MIJ_BENCH_WATCHDOG_S": "45"})
     assert d["config"]["gather"] == "sendrecv" and expect in d["gather_fallback"], d["gather_fallback"]
     assert d["jpeg_crc32"] == one_gpu_line["jpeg_crc32"] and "starting fresh ranks" in err
+
+
+# ---- progressive output over N ranks (round 5) --------------------------------------------------------------------------------------
+def _progressive_worker(rank, world, port, W, H, css, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nvjpeg_imagecompressor_amd as mij
+    from nvjpeg_imagecompressor_amd import sharded
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    enc = sharded.make_hip_strip_encoder(torch, W, H, 95, True, css, rank, world, 0, "rgb", progressive=True)
+    strip = None
+    if enc is not None:
+        g = enc.geometry
+        d_img = torch.empty((g["strip_rows"], W, 3), dtype=torch.uint8, device=dev)
+        mij.synth_image_device(d_img.data_ptr(), W, g["strip_y0"], g["strip_rows"], W * 3, bgr=False)
+        torch.cuda.synchronize()
+        strip = sharded.HipProgressiveStrip(torch, enc, d_img, "rgb")
+    out = None
+    cache = {"device": dev}
+    for _ in range(2):          # twice: buffers, statistics and tables are reused across images
+        out = sharded.encode_step_progressive(torch, dist, strip, cache, torch.cuda.current_stream().cuda_stream)
+    if rank == 0:
+        open(out_path, "wb").write(out.cpu().numpy().tobytes())
+        open(out_path + ".ri", "w").write(str(enc.geometry["restart_interval"]))
+    dist.barrier()
+    if enc is not None:
+        enc.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,css,H", [(2, 1, 1000), (3, 2, 1000), (5, 1, 2504), (3, 0, 488), (4, 1, 250)])
+def test_progressive_n_ranks_equal_the_one_shot_file(oracle, tmp_path, world, css, H):
+    """The reference's own encoding (progressive, ImageCompressorImpl.cu:28) over N ranks with HIP strips: ten scans' statistics in one
+    all-reduce, ten segments per rank placed scan by scan -- byte-identical to the oracle's (= libjpeg's) one-shot file with the same
+    restart interval, and to what ONE rank writes through mij_encode_entropy. (4, 1, 250): the last strip owns clipped block rows and a
+    bottom edge; (3, 0, 488): 4:4:4.)"""
+    import numpy as np
+    W = 2080
+    out = tmp_path / "prog.jpg"
+    mp.spawn(_progressive_worker, args=(world, _free_port(), W, H, css, str(out)), nprocs=world, join=True)
+    ri = int(open(str(out) + ".ri").read())
+    want = oracle.encode_progressive(oracle.synth_rgb(W, H), 95, css, ri)
+    got = out.read_bytes()
+    assert len(got) == len(want) and got == want
+    import nvjpeg_imagecompressor_amd as mij
+    d = torch.from_numpy(oracle.synth_rgb(W, H)).cuda()
+    with mij.Encoder(W, H, 95, True, css, restart_interval=ri, progressive=True) as enc:       # one rank, the whole-image path
+        enc.encode_device(d.data_ptr(), W * 3, "rgb")
+        assert enc.retrieve() == want
+    with mij.Encoder(W, H, 95, True, css, restart_interval=ri, progressive=True) as enc:       # one rank through the strip protocol
+        enc.transform(d.data_ptr(), W * 3, "rgb")
+        enc.prog_statistics()
+        sizes, hdr = enc.prog_emit()
+        from nvjpeg_imagecompressor_amd import sharded
+        offs, total = sharded.progressive_offsets([sizes], hdr)
+        enc.prog_place(offs[0], 0, 0, total, 3)
+        assert enc.retrieve() == want
+
+
+def test_progressive_strip_needs_an_interval_that_divides_the_row(mij):
+    with pytest.raises(mij.MiJpegError):
+        mij.Encoder(2080, 1000, 95, True, 1, restart_interval=64, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)     # 130 MCUs per row
+    with mij.Encoder(2080, 1000, 95, True, 1, restart_interval=65, strip_mcu_row0=8, strip_mcu_rows=8, progressive=True) as e:
+        assert e.geometry["strip_y0"] == 64

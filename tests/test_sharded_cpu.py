@@ -245,3 +245,137 @@ def test_partition_arithmetic():
     assert sharded.rows_per_restart_unit(520, 64) == 8      # the headline configuration: 625 strips of 8 MCU rows to share out
     assert sharded.rows_per_restart_unit(520, 1040) == 2
     assert sharded.rows_per_restart_unit(26, 40) == 20      # 40 MCUs and 26 per row meet again after 20 rows
+
+
+# ---- progressive output, sharded (round 5): the orchestration of sharded.encode_step_progressive on CPU -------------------------
+def _cut_progressive(jpg, geo, ri, W, H):
+    """The oracle's whole-image progressive file taken apart: header_bytes[10] (what stands in front of each scan's data), and per scan
+    the list of its restart intervals as byte strings (each with the RSTn that follows it; the last one has none)."""
+    pos, hdrs, scans, start = 2, [], [], 0
+    n = len(jpg)
+    while pos < n:
+        assert jpg[pos] == 0xFF, pos
+        m = jpg[pos + 1]
+        if m == 0xD9:
+            break
+        ln = (jpg[pos + 2] << 8) | jpg[pos + 3]
+        pos += 2 + ln
+        if m == 0xDA:
+            hdrs.append(pos - start)
+            a = pos
+            ivs = []
+            while True:           # entropy-coded data: up to the next marker that is neither a stuffed zero nor RSTn
+                while not (jpg[pos] == 0xFF and jpg[pos + 1] != 0x00):
+                    pos += 1
+                if 0xD0 <= jpg[pos + 1] <= 0xD7:
+                    pos += 2
+                    ivs.append(bytes(jpg[a:pos]))
+                    a = pos
+                else:
+                    ivs.append(bytes(jpg[a:pos]))
+                    break
+            scans.append(ivs)
+            start = pos
+    assert len(scans) == 10 and len(hdrs) == 10
+    return hdrs, scans
+
+
+class OracleProgressiveStrip:
+    """Plays HipProgressiveStrip on CPU: rank `rank`'s restart intervals of every scan, cut out of the oracle's whole-image file (test
+    infrastructure: what is under test is the offsets arithmetic, the one all-reduce and the transport)."""
+
+    def __init__(self, O, W, H, q, css, ri, r0, r1, geo, rank):
+        self.rank = rank
+        jpg = O.encode_progressive(O.synth_rgb(W, H), q, css, ri)
+        self.whole = jpg
+        self.hdr_len, scans = _cut_progressive(jpg, geo, ri, W, H)
+        self.hdr_bytes, pos = [], 0
+        for i in range(10):
+            self.hdr_bytes.append(jpg[pos:pos + self.hdr_len[i]])
+            pos += self.hdr_len[i] + sum(len(b) for b in scans[i])
+        hs, vs, mcux, mcuy = geo["hs"], geo["vs"], geo["mcux"], geo["mcuy"]
+        script = [(3, 0), (1, 0), (1, 2), (1, 1), (1, 0), (1, 0), (3, 0), (1, 2), (1, 1), (1, 0)]      # (components, first component) of libjpeg's ten scans
+        self.segs = []
+        for i, (nc, c) in enumerate(script):
+            if nc == 3:
+                per_row, rows_all, k = mcux // ri, mcuy, 1
+            elif c == 0:
+                per_row, rows_all, k = (mcux * hs) // ri, (H + 7) // 8, vs
+            else:
+                per_row, rows_all, k = mcux // ri, ((H + vs - 1) // vs + 7) // 8, 1
+            a, b = min(r0 * k, rows_all) * per_row, min(r1 * k, rows_all) * per_row
+            assert (mcux * (hs if (nc == 1 and c == 0) else 1)) % ri == 0
+            self.segs.append(b"".join(scans[i][a:b]))
+        self.last = r1 == mcuy
+
+    def statistics(self, stream=0):
+        h = torch.zeros(10 * 4 * 257, dtype=torch.int32)
+        h[0] = self.rank + 1
+        self.hist = h
+        return h
+
+    def emit(self, stream=0):
+        return [len(s) for s in self.segs], list(self.hdr_len)
+
+    def place_into(self, buf, offsets, file_bytes, flags, stream=0):
+        for i in range(10):
+            buf[offsets[i]:offsets[i] + len(self.segs[i])] = torch.frombuffer(bytearray(self.segs[i]), dtype=torch.uint8)
+            if flags & 1:
+                buf[offsets[i] - self.hdr_len[i]:offsets[i]] = torch.frombuffer(bytearray(self.hdr_bytes[i]), dtype=torch.uint8)
+        if flags & 2:
+            buf[file_bytes - 2] = 0xFF
+            buf[file_bytes - 1] = 0xD9
+
+    def place_staged(self, sizes, stream=0):
+        return [torch.frombuffer(bytearray(s), dtype=torch.uint8) if len(s) else torch.zeros(0, dtype=torch.uint8) for s in self.segs]
+
+
+def _progressive_worker(rank, world, port, W, H, css, ri, q, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from nvjpeg_imagecompressor_amd import sharded
+    geo = O.geometry(W, H, css)
+    assert sharded.progressive_strip_interval(geo["mcux"]) == ri
+    r0, r1 = sharded.partition_mcu_rows(geo["mcuy"], world, rank, 1)
+    strip = OracleProgressiveStrip(O, W, H, q, css, ri, r0, r1, geo, rank) if r1 > r0 else None
+    out = sharded.encode_step_progressive(torch, dist, strip, {})
+    if strip is not None:       # the one collective summed every owner's statistics in place
+        owners = sum(1 for r in range(world) if sharded.partition_mcu_rows(geo["mcuy"], world, r, 1)[1] > sharded.partition_mcu_rows(geo["mcuy"], world, r, 1)[0])
+        assert int(strip.hist[0]) == owners * (owners + 1) // 2
+    if rank == 0:
+        open(out_path, "wb").write(out.numpy().tobytes())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("css,H", [(1, 250), (2, 250), (0, 64)])
+def test_progressive_n_rank_file_equals_one_rank_file(oracle, tmp_path, world, css, H):
+    """Progressive output over N ranks (ImageCompressorImpl.cu:28 is the reference's own encoding): statistics of the ten scans in ONE
+    all-reduce, sizes matrix all-gathered, segments placed scan by scan, ranks in order -- the file of the one-shot encoder, byte for
+    byte. H = 250 is not a multiple of the MCU height (the last strip owns the clipped block rows of the single-component scans);
+    (0, 64): 8 MCU rows for 8 ranks, one each."""
+    W, q = 208, 92
+    geo = oracle.geometry(W, H, css)
+    ri = geo["mcux"]          # = progressive_strip_interval: 26 (4:4:4) or 13 MCUs per row, the interval must divide it
+    out = tmp_path / "prog.jpg"
+    if world == 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    mp.spawn(_progressive_worker, args=(world, _free_port(), W, H, css, ri, q, str(out)), nprocs=world, join=True)
+    want = oracle.encode_progressive(oracle.synth_rgb(W, H), q, css, ri)
+    assert out.read_bytes() == want
+
+
+def test_progressive_offsets_arithmetic():
+    from nvjpeg_imagecompressor_amd import sharded
+    sizes = [[10 + r + i for i in range(10)] for r in range(3)]
+    hdr = [100] + [30] * 9
+    offs, total = sharded.progressive_offsets(sizes, hdr)
+    assert offs[0][0] == 100 and offs[1][0] == 110 and offs[2][0] == 121
+    assert offs[0][1] == 100 + (10 + 11 + 12) + 30
+    assert total == sum(hdr) + sum(sum(r) for r in sizes) + 2
+    assert sharded.progressive_strip_interval(520) == 520 and sharded.progressive_strip_interval(1040) == 520 and sharded.progressive_strip_interval(2080) == 520
+    assert sharded.progressive_strip_interval(13) == 13

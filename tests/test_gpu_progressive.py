@@ -67,7 +67,7 @@ def test_progressive_strips_need_an_aligned_interval(mij):
     """Round 5: a progressive encoder may own a strip when every scan's restart intervals end at the strip's boundaries -- the interval
     divides the MCUs per row and the width is a whole number of MCUs (tests/test_gpu_sharded.py encodes with such strips)."""
     with pytest.raises(mij.MiJpegError, match="divides the MCUs per row"):
-        mij.Encoder(2080, 1000, 95, True, 1, restart_interval=64, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)     # 130 MCUs per row
+        mij.Encoder(2080, 1000, 95, True, 1, restart_interval=64, strip_mcu_row0=0, strip_mcu_rows=32, progressive=True)    # 130 MCUs per row: 32 rows are whole intervals of the interleaved scans, not of the luma scans
     with pytest.raises(mij.MiJpegError, match="whole MCUs"):
         mij.Encoder(520, 512, 90, True, 1, restart_interval=33, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)       # 65 luma blocks, 33 MCUs per row
     with mij.Encoder(512, 512, 90, True, 0, strip_mcu_row0=8, strip_mcu_rows=8, progressive=True) as e:                    # AUTO = 64 = the MCU row here

@@ -475,7 +475,7 @@ def worker_one_gpu(args):
     drain()
     fence()
     # The shader clock needs tens of milliseconds of THIS load to settle (from idle the first ~20 images of the loop run 5-25 % slower
-    # while it ramps, tools/r4_clock_transient.py): W warm-up steps of 1.1 ms each do not get there. So, still untimed, the same loop
+    # while it ramps, tools/clock_transient.py): W warm-up steps of 1.1 ms each do not get there. So, still untimed, the same loop
     # runs on in rounds of ten steps until two successive clock readings agree within 1 % (at most `--settle-rounds` rounds).
     settle_steps = 0
     clocks.append(_clock(torch, mij, "after the warm-up steps"))
@@ -1310,7 +1310,7 @@ def cpu_baseline_fields(args, optimize, restart_interval, jpeg_crc32, jpeg_bytes
 def golden_fingerprint(args, optimize, restart_interval):
     """(crc32 hex, bytes) of this configuration's file from tests/golden/big_8320x40000_q95.json (written by
     tests/make_golden_big.py on the CPU), or None when the run is not one of its configurations."""
-    if (args.width, args.height, args.quality) != (W_IMG, H_IMG, QUALITY) or args.progressive or args.fmt not in ("bgr", "rgb"):
+    if (args.width, args.height, args.quality) != (W_IMG, H_IMG, QUALITY) or args.fmt not in ("bgr", "rgb"):
         return None
     path = os.path.join(ROOT, "tests", "golden", "big_8320x40000_q95.json")
     try:
@@ -1319,7 +1319,7 @@ def golden_fingerprint(args, optimize, restart_interval):
     except (OSError, ValueError):
         return None
     css = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5}[args.css]
-    e = d.get("cases", {}).get("css%d_ri%d_%s" % (css, restart_interval, "opt" if optimize else "fix"))
+    e = d.get("cases", {}).get("css%d_ri%d_%s" % (css, restart_interval, "progressive" if args.progressive else "opt" if optimize else "fix"))
     if not isinstance(e, dict) or "crc32" not in e:
         return None
     return (e["crc32"], e.get("len"))

@@ -347,3 +347,15 @@ def test_progressive_strip_needs_an_interval_that_divides_the_row(mij):
         mij.Encoder(2080, 1000, 95, True, 1, restart_interval=64, strip_mcu_row0=0, strip_mcu_rows=8, progressive=True)     # 130 MCUs per row
     with mij.Encoder(2080, 1000, 95, True, 1, restart_interval=65, strip_mcu_row0=8, strip_mcu_rows=8, progressive=True) as e:
         assert e.geometry["strip_y0"] == 64
+
+
+def test_progressive_fullsize_three_ranks_by_crc(tmp_path):
+    """BASELINE's image in the reference's own encoding over three ranks (one GPU here, gloo): the committed fingerprint of the CPU
+    oracle's one-shot file at the sharded interval (tests/golden/big_8320x40000_q95.json, css1_ri520_progressive)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "big_8320x40000_q95.json")))["cases"]["css1_ri520_progressive"]
+    out = tmp_path / "prog_full.jpg"
+    mp.spawn(_progressive_worker, args=(3, _free_port(), 8320, 40000, 1, str(out)), nprocs=3, join=True)
+    assert int(open(str(out) + ".ri").read()) == 520
+    got = out.read_bytes()
+    assert (len(got), "%08x" % zlib.crc32(got)) == (gold["len"], gold["crc32"])

@@ -811,7 +811,7 @@ def section_decode(args, torch, mij, d_img, d_file, copy_gbs):
                                         "frac_of_copy_ceiling": round(gbs / copy_gbs, 4) if copy_gbs else None,
                                         "algorithmic_bytes": alg, "note": "algorithmic bytes = file + 3*W*H pixels written; device time of the whole decode "
                                         "(mij_decode_sync: events around all its kernels), median of 5 after 2 warm-up decodes. Huffman decoding is "
-                                        "bound by instruction issue / serial dependence, not by HBM (DESIGN.md section 4)"}}
+                                        "bound by instruction issue / serial dependence, not by HBM (DESIGN.md section 6)"}}
         if not args.no_progressive_decode:
             from PIL import Image, ImageFile
             Image.MAX_IMAGE_PIXELS = None

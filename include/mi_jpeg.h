@@ -75,9 +75,9 @@ typedef struct mij_encoder_params {
   /* nvjpegEncoderParamsSetEncoding (ImageCompressorImpl.cu:28): 0 = baseline sequential (SOF0, one scan), the default
    * and the fast path; 1 = progressive (SOF2): the same coefficients coded as the ten scans of libjpeg's default script
    * with an optimal Huffman table per scan -- byte-identical to libjpeg-turbo's progressive output, a few per cent
-   * smaller than baseline, about three times slower to produce (a statistics and an emit pass per scan; see DESIGN.md section 4
-   * for the measured times). Whole images only (no strips);
-   * optimized_huffman is implied. */
+   * smaller than baseline, about three times slower to produce (a statistics and an emit pass per scan; see DESIGN.md section 5
+   * for the measured times). Whole images, or strips when restart_interval divides the MCUs per row and the width is a whole
+   * number of MCUs ("Progressive output in STRIPS" below); optimized_huffman is implied. */
   int progressive;
 } mij_encoder_params;
 #define MIJ_ENCODER_PARAMS_INIT {(uint32_t)sizeof(mij_encoder_params), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
@@ -155,7 +155,7 @@ MIJ_API int mij_set_histogram_buffer(mij_encoder *enc, uint32_t *d_hist);
  * area. Every other rank passes the root's scan area as it sees it through a peer mapping (mij_ipc_export on the root,
  * mij_ipc_open on the others) and writes its strip there at its own offset. The root may differ from image to image: a
  * root receives (world - 1) / world of every file it assembles over its inbound links, so rotating it spreads that load
- * (DESIGN.md section 5). The file is complete on the root once every rank's mij_encode_place has executed -- e.g. when a
+ * (DESIGN.md section 7). The file is complete on the root once every rank's mij_encode_place has executed -- e.g. when a
  * later collective on the same streams completes. mij_sharded_result waits for this handle's part and reports the file
  * (the root of the handle's last image) / the strip (others). */
 MIJ_API int mij_encode_entropy_sizes(mij_encoder *enc, uint64_t *d_size_slot, void *stream);
@@ -166,7 +166,7 @@ MIJ_API int mij_sharded_result(mij_encoder *enc, const uint64_t *d_sizes, int ra
  * [1] the put of the strip into the root's peer-mapped buffer (0 on the root). Strip bytes / [1] = what one xGMI link gave. */
 MIJ_API int mij_place_times(mij_encoder *enc, float ms[2]);
 /* mij_encoder_reserve_output allocates the buffer device-UNCACHED (hipDeviceMallocUncached) when it can: other GPUs write into it
- * behind this GPU's caches, so no line of it may live in them (DESIGN.md section 5). mij_output_is_uncached tells (1 / 0). */
+ * behind this GPU's caches, so no line of it may live in them (DESIGN.md section 7). mij_output_is_uncached tells (1 / 0). */
 MIJ_API int mij_encoder_reserve_output(mij_encoder *enc, size_t scan_capacity_bytes);
 MIJ_API int mij_output_is_uncached(const mij_encoder *enc);
 MIJ_API int mij_output_buffer(mij_encoder *enc, void **d_buffer, size_t *scan_offset, size_t *scan_capacity);

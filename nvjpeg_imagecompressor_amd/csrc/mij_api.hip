@@ -316,7 +316,7 @@ int mij_encoder_create(const mij_encoder_params *p_in, mij_encoder **out) {
   CRCHK(hipMalloc(&e->d_redo, sizeof(uint32_t)));
   CRCHK(hipMemset(e->d_redo, 0, sizeof(uint32_t)));
   // Opt-in experiment (MIJ_FUSE=1): K4 with the size scan and the stuffing + compaction folded in (decoupled look-back).
-  // Measured SLOWER than the three separate kernels (0.91 vs 0.59 + 0.01 + 0.10 ms, DESIGN.md section 4): the placement work is a
+  // Measured SLOWER than the three separate kernels (0.91 vs 0.59 + 0.01 + 0.10 ms, DESIGN.md section 9): the placement work is a
   // latency-bound chain per interval that K6 runs at 32 waves per CU and the fused kernel at 16, on top of the coder.
   e->fuse = getenv("MIJ_FUSE") != nullptr;
   CRCHK(hipMalloc(&e->d_out, HDR_AREA + e->capacity + 64));
@@ -877,7 +877,7 @@ int mij_encode_entropy(mij_encoder *e, void *stream) {
   return MIJ_OK;
 }
 
-// ---- strip sharding without host round trips (SURVEY.md 8e; DESIGN.md section 5) ------------------------------------
+// ---- strip sharding without host round trips (SURVEY.md 8e; DESIGN.md section 7) ------------------------------------
 // The one-GPU entry points above learn the strip size on the host (mij_encode_result) -- fine for one GPU, a pipeline
 // stall per image when N ranks must agree on offsets. These three keep sizes and offsets on the device:
 //   mij_encode_entropy_sizes : tables + entropy coding + size scan; the strip's byte count lands in *d_size_slot
@@ -1003,7 +1003,7 @@ int mij_encoder_reserve_output(mij_encoder *e, size_t scan_capacity) {
   // k_put read from there). So the buffer is allocated UNCACHED for its owner (hipDeviceMallocUncached: MTYPE UC, no line of it
   // ever lives in an L2 or L1 of this device) -- what RCCL does with its own peer-written buffers -- and visibility of a peer's
   // bytes then rests on two things only, both in program order: k_put's system-scope release before it retires, and the
-  // collective the peer enqueues behind it, which this rank's stream waits for (DESIGN.md section 5). A cached allocation would
+  // collective the peer enqueues behind it, which this rank's stream waits for (DESIGN.md section 7). A cached allocation would
   // lean on the fabric probing this device's L2 on remote writes; no multi-GPU run has ever tested that here.
   // MIJ_SHARED_OUT=cached keeps plain hipMalloc (A/B experiments on one GPU); if the uncached allocation or its export fails the
   // plain one is taken as well.

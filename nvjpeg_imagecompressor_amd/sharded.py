@@ -511,7 +511,7 @@ def _buffer(torch, cache, n, device):
 def progressive_strip_interval(mcus_per_row):
     """Restart interval of a SHARDED progressive encode: it must divide the MCUs per row (every one of the ten scans then cuts into
     restart intervals at strip boundaries; mi_jpeg.h). The largest divisor up to 1024 MCUs: long intervals suit the progressive coder
-    (DESIGN.md section 4: 520 at the headline width, where one rank alone picks 640)."""
+    (DESIGN.md section 5: 520 at the headline width, where one rank alone picks 640)."""
     best = 1
     for d in range(1, min(mcus_per_row, 1024) + 1):
         if mcus_per_row % d == 0:

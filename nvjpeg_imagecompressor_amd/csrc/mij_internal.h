@@ -165,6 +165,8 @@ struct ScanDesc {
   int ri;              // MCUs (of this scan) per restart interval; 0 = no restart markers
   int bw, bh;          // single-component scan: that component's block grid (T.81 A.2.2: ceil(samples / 8))
   long long nmcu;      // MCUs of this scan
+  int px_g;            // parallel progressive decoder only (k_decode_prog.inc): blocks between two anchors of this refinement scan
+                       // (px_anchor_spacing; 0 = not set)
 };
 
 hipError_t launch_scan_decode(const Geom &g, const ScanDesc &sd, const uint8_t *scan, size_t n, const unsigned long long *seg_pos,

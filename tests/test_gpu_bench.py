@@ -64,3 +64,29 @@ def test_fixed_tables_and_progressive_lines():
     assert d["roofline"]["stage_A_alone"]["avg_launch_ms"] > 0          # the headline kernel IS stage A alone here
     p = _bench(SMALL + ["--progressive"])
     assert p["loop"] == "progressive" and "stage_A_alone" not in p["roofline"] and p["per_kernel_pass"]["file_identical_to_timed_loop"] is True
+
+
+def test_driver_line_carries_every_single_gpu_config_and_both_decoders():
+    """Round 5: the default workload's line holds BASELINE configs 3 and 5 and both decoders, each checked against a committed golden or
+    against a stock decoder inside the run (the CPU legs are switched off here; the driver's command runs them too)."""
+    d = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--kernel-pass", "2", "--stage-a-pass", "2"], timeout=900)
+    assert d["golden_match"] is True and d["untimed_steps"] >= 1
+    rows = d["configs"]["table1"]["rows"]
+    assert sorted(rows) == ["411", "420", "422", "440", "444"]
+    for css, r in rows.items():
+        assert r["golden_match"] is True and r["steps"] >= 10 and 0.3 < r["K1_frac"] < 1 and 0.2 < r["K4_frac"] < 1 and r["decode_ms"] > 0, (css, r)
+    assert abs(rows["422"]["psnr_db"] - 31.162) < 0.01 and rows["422"]["crc32"] == d["jpeg_crc32"]
+    sec = d["configs"]["secondary"]
+    assert sec["first_layer"]["golden_match"] is True
+    for key in ("q95_css1_gain1", "q98_css0_gain1"):
+        c = sec["cases"][key]
+        assert c["golden_match"] is True and c["secondary_compress_ms"] > 0 and c["decode_both_and_add_ms"] > 0
+        assert [round(x, 2) for x in (c["psnr_first_layer_db"], c["psnr_both_layers_db"])] == [round(x, 2) for x in c["golden_psnr_db"]]
+    own = d["decode"]["own_file"]
+    assert own["identical_to_pillow"] is True and own["roofline"]["algorithmic_bytes"] == d["jpeg_bytes"] + 3 * 8320 * 40000 and 0 < own["roofline"]["frac"] < 1
+    prog = d["decode"]["progressive_nodri"]
+    assert prog["golden_match"] is True and prog["scans_parallel"] == prog["scans_tried"] == 9 and prog["device_ms"] < 1000
+    v = d["roofline"].get("valu_issue")
+    if v is not None and v["model"] == "bound":          # (only when profiles/ holds the class file of THIS build)
+        k = v["kernels"]["k_transform"]
+        assert k["bound_ms"] < k["launch_ms"] and 2.0 <= k["bound_cycles_per_instruction"] <= 4.0 <= k["cycles_per_valu_instruction"] + 1.0

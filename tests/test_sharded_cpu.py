@@ -352,7 +352,7 @@ def _progressive_worker(rank, world, port, W, H, css, ri, q, out_path):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-@pytest.mark.parametrize("css,H", [(1, 250), (2, 250), (0, 64)])
+@pytest.mark.parametrize("css,H", [(1, 250), (2, 250), (0, 64), (2, 64)])      # (2, 64): four MCU rows -- at world 8 four ranks own nothing
 def test_progressive_n_rank_file_equals_one_rank_file(oracle, tmp_path, world, css, H):
     """Progressive output over N ranks (ImageCompressorImpl.cu:28 is the reference's own encoding): statistics of the ten scans in ONE
     all-reduce, sizes matrix all-gathered, segments placed scan by scan, ranks in order -- the file of the one-shot encoder, byte for

@@ -812,6 +812,34 @@ def section_decode(args, torch, mij, d_img, d_file, copy_gbs):
                                         "algorithmic_bytes": alg, "note": "algorithmic bytes = file + 3*W*H pixels written; device time of the whole decode "
                                         "(mij_decode_sync: events around all its kernels), median of 5 after 2 warm-up decodes. Huffman decoding is "
                                         "bound by instruction issue / serial dependence, not by HBM (DESIGN.md section 6)"}}
+        # throughput with two files in flight (two handles, one host thread and one stream each): the dense passes of one decode are a single round
+        # of 3.7 waves per SIMD, so a second file fills what the first leaves idle
+        try:
+            import threading
+            with mij.Decoder() as dec2:
+                outs = [d_out, torch.empty_like(d_out)]
+                sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+                decs, reps = [dec, dec2], 8
+
+                def work(k):
+                    for _ in range(reps):
+                        decs[k].decode_device_ptr(d_file.data_ptr(), nfile, outs[k].data_ptr(), W * 3, "rgb", 0, sts[k].cuda_stream)
+                        decs[k].sync()
+                for k in range(2):
+                    decs[k].decode_device_ptr(d_file.data_ptr(), nfile, outs[k].data_ptr(), W * 3, "rgb", 0, sts[k].cuda_stream)
+                    decs[k].sync()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+                [t.start() for t in th]
+                [t.join() for t in th]
+                torch.cuda.synchronize()
+                out["own_file"]["two_in_flight"] = {"ms_per_file": round((time.perf_counter() - t0) / (2 * reps) * 1e3, 3), "files": 2 * reps,
+                                                    "identical_outputs": bool(torch.equal(outs[0], outs[1])),
+                                                    "note": "wall time per file with two decoder handles in flight, one host thread and stream each"}
+                del outs
+        except Exception as ex:      # noqa: BLE001
+            out["own_file"]["two_in_flight"] = {"error": repr(ex)[:200]}
         if not args.no_progressive_decode:
             from PIL import Image, ImageFile
             Image.MAX_IMAGE_PIXELS = None

@@ -260,6 +260,13 @@ def test_bench_multi_rank_rehearsal(one_gpu_line, gather, comms):
         # one image per root before the timed region and one per root after it, all equal to the timed region's file
         assert d["files_verified"]["roots"] == 3 and d["files_verified"]["images"] == 6 and d["files_verified"]["identical_to_timed_file"] is True
         assert d["put_GB/s"]["samples"] >= 2 and d["put_GB/s"]["min"] > 0
+        # round 5: what the root takes in per image, so that a first multi-GPU run explains itself
+        ri = d["root_inbound"]
+        assert len(ri["strip_bytes_per_rank"]) == 3 and sum(ri["strip_bytes_per_rank"]) > 0
+        assert ri["inbound_bytes_per_image"] == sum(ri["strip_bytes_per_rank"]) - ri["strip_bytes_per_rank"][ri["root"]]
+    assert sorted(d["per_rank_total_ms"]) == ["0", "1", "2"]
+    if d["slowest_rank"] is not None:
+        assert d["slowest_rank"]["stage_ms"]["total"] == max(v for v in d["per_rank_total_ms"].values() if v)
 
 
 def test_bench_under_an_external_launcher(one_gpu_line):
